@@ -1,0 +1,109 @@
+/* yolo_hip.h - C-ABI of libyolo_hip.so: the MI355X (gfx950) YOLOv3 inference hot path.
+ *
+ * The reference (FenHua/yolo, yolo_v3/) has no FFI of its own: its boundary is a set of Python
+ * functions that build TF-1 graphs.  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference checkout).  The Python mirror in yolo_amd/ binds
+ * these with ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All tensor pointers are DEVICE pointers (hipMalloc / torch-ROCm memory) unless marked HOST.
+ *  - Caller allocates inputs, outputs and workspaces; the library keeps no reference to them after
+ *    the call returns.  Only the weight handle (YoloNet / YoloConv) owns device memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every entry enqueues
+ *    asynchronously and never synchronises the device.
+ *  - Layout NHWC, float32 at the boundary (images RGB in [0,1]; boxes x_min,y_min,x_max,y_max in
+ *    network-input pixels; labels int32) exactly like the reference.
+ *  - Return value: YOLO_OK or a negative YOLO_ERR_*; yolo_last_error() gives a message (thread-local).
+ */
+#ifndef YOLO_HIP_H_
+#define YOLO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    YOLO_OK = 0,
+    YOLO_ERR_ARG = -1,         /* null pointer / non-positive size */
+    YOLO_ERR_SHAPE = -2,       /* shape not supported (H,W must be multiples of 32, ...) */
+    YOLO_ERR_HIP = -3,         /* a HIP runtime call failed */
+    YOLO_ERR_UNSUPPORTED = -4, /* parameter outside the implemented range */
+    YOLO_ERR_WORKSPACE = -5    /* workspace too small */
+};
+
+enum { YOLO_DTYPE_F32 = 0, YOLO_DTYPE_BF16 = 1 };   /* arithmetic type of the conv stack */
+enum { YOLO_NMS_TF = 0, YOLO_NMS_PY = 1 };          /* gpu_nms (TF op) / cpu_nms+py_nms semantics */
+
+typedef struct YoloNet YoloNet;
+typedef struct YoloConv YoloConv;
+
+const char* yolo_last_error(void);
+int yolo_abi_version(void);
+
+/* ---- whole network: replaces yolov3.forward (yolo_v3/model.py:21-67), i.e. darknet53_body +
+ * yolo_block + upsample_layer + concat (yolo_v3/utils/layer_utils.py:9-72), and the weight
+ * ingestion of load_weights (yolo_v3/utils/misc_utils.py:45-96).
+ * darknet_stream: HOST float32 body of a Darknet .weights file (after the 5 x int32 header), conv
+ * order = call order of forward; n_floats must match the architecture exactly. */
+int yolo_net_create(int class_num, int dtype, const float* darknet_stream, size_t n_floats, YoloNet** out);
+int yolo_net_destroy(YoloNet* net);
+/* Bytes of activation workspace forward needs for a [B,H,W,3] input (0 on bad shape). */
+size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int W);
+/* images [B,H,W,3] f32 -> fm1 [B,H/32,W/32,3*(5+C)], fm2 [B,H/16,W/16,.], fm3 [B,H/8,W/8,.] f32. */
+int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
+                     size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream);
+/* Number of conv layers of the plan (75 for YOLOv3). */
+int yolo_net_num_layers(const YoloNet* net);
+
+/* ---- one conv layer: replaces conv2d (yolo_v3/utils/layer_utils.py:9-21) under the arg_scope of
+ * yolo_v3/model.py:32-36 (conv no-bias + BN(eps 1e-5, inference) + leaky 0.1), or, with bn == 0,
+ * the detection conv of model.py:42-44 (conv + bias, no activation).
+ * weights_hwio: HOST [k,k,Cin,Cout] f32 (TF variable layout).  bn != 0: p0..p3 = beta, gamma,
+ * moving_mean, moving_variance (HOST, [Cout]); bn == 0: p0 = bias, p1..p3 ignored. */
+int yolo_conv_create(int dtype, int cin, int cout, int ksize, int stride, int bn,
+                     const float* weights_hwio, const float* p0, const float* p1, const float* p2,
+                     const float* p3, YoloConv** out);
+int yolo_conv_destroy(YoloConv* conv);
+/* in: [B,H,W,Cin] f32; residual (optional, same shape as out, added AFTER the activation like
+ * res_block, layer_utils.py:24-29) -> out [B,Ho,Wo,Cout] f32.  In bf16 mode the input is rounded to
+ * bf16 first (scratch: workspace of yolo_conv_workspace_bytes). */
+size_t yolo_conv_workspace_bytes(const YoloConv* conv, int B, int H, int W);
+int yolo_conv_forward(YoloConv* conv, const float* in, int B, int H, int W, const float* residual,
+                      float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- replaces upsample_layer (layer_utils.py:67-72) for the exact-2x case the network uses. */
+int yolo_upsample2x(const float* in, int B, int H, int W, int C, float* out, void* stream);
+
+/* ---- decode: replaces yolov3.reorg_layer + yolov3.predict (yolo_v3/model.py:69-153) and,
+ * when scores != NULL, the caller's `pred_confs * pred_probs` (yolo_v3/test_single_image.py:38).
+ * anchors: HOST float32 [9,2] (w,h) as parsed by parse_anchors (misc_utils.py:10-13).
+ * boxes [B,n,4], confs [B,n,1], probs [B,n,C], scores [B,n,C]; n = 3*(g1^2+g2^2+g3^2). */
+int yolo_decode(const float* fm1, const float* fm2, const float* fm3, int B, int H, int W,
+                int class_num, const float* anchors, float* boxes, float* confs, float* probs,
+                float* scores, void* stream);
+
+/* reorg_layer alone (model.py:69-108) for ONE feature map [B,gh,gw,3*(5+C)] and its 3 anchors (HOST [3,2]):
+ * boxes [B,gh,gw,3,4] = (center_x, center_y, w, h) in input pixels.  conf/prob logits are slices of fm. */
+int yolo_reorg_boxes(const float* fm, int B, int gh, int gw, int H, int W, int class_num,
+                     const float* anchors3, float* boxes, void* stream);
+
+/* ---- per-class NMS: replaces gpu_nms (yolo_v3/utils/nms_utils.py:7-37, i.e. the score mask +
+ * tf.image.non_max_suppression per class) with mode YOLO_NMS_TF, and cpu_nms/py_nms
+ * (nms_utils.py:40-90) with mode YOLO_NMS_PY.
+ * boxes [B,n,4], scores [B,n,C]: each of the B images is processed independently (the reference's
+ * batch-flattening behaviour is obtained by calling with B=1, n=B*n).
+ * Outputs per image i at rows [i*C*max_boxes, ...): class-ascending, selection order inside a class;
+ * out_counts[i] = number of valid rows; out_index = index of the box inside its image (keep-index). */
+size_t yolo_nms_workspace_bytes(int B, int n, int class_num, int max_boxes);
+int yolo_nms(const float* boxes, const float* scores, int B, int n, int class_num, int max_boxes,
+             float score_thresh, float iou_thresh, int mode, float* out_boxes, float* out_scores,
+             int32_t* out_labels, int32_t* out_index, int32_t* out_counts, void* workspace,
+             size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H_ */

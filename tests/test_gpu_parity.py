@@ -1,0 +1,369 @@
+"""GPU parity tests: the HIP path (through the C-ABI via yolo_amd) against the CPU oracle and the
+golden fixtures.  Run on the MI355X box:  python -u -m pytest tests -m gpu -x -v --timeout 120
+Tolerances: fp32 conv stack / decode  |a-b| <= 1e-3*|b| + 1e-3*rms(b)   (north_star: 1e-3 relative);
+bf16: single layer |a-b| <= 4e-2*|b| + 4e-2*rms(b); whole 75-layer stack |a-b| <= 1e-1*(|b| + rms(b)) and
+rms(a-b) <= 3e-2*rms(b);   NMS: bit-exact indices, boxes, scores, labels."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_rms_ok
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def net_f32(torch_cuda, oracle, weight_stream):
+    from yolo_amd.model import yolov3
+    return yolov3(80, oracle.YOLO_ANCHORS, dtype="fp32").load_weight_stream(weight_stream)
+
+
+@pytest.fixture(scope="module")
+def net_bf16(torch_cuda, oracle, weight_stream):
+    from yolo_amd.model import yolov3
+    return yolov3(80, oracle.YOLO_ANCHORS, dtype="bf16").load_weight_stream(weight_stream)
+
+
+# ---------------------------------------------------------------------------------------------
+# single conv layers
+# ---------------------------------------------------------------------------------------------
+def _conv_case(torch, oracle, dtype, cin, cout, k, stride, bn, B, H, W, residual, seed):
+    from yolo_amd import _lib, _tensor
+    rng = np.random.default_rng(seed)
+    w = rng.normal(0, np.sqrt(2.0 / (k * k * cin)), (k, k, cin, cout)).astype(np.float32)
+    p = dict(w=w)
+    if bn:
+        p.update(beta=rng.normal(0, 0.1, cout).astype(np.float32), gamma=rng.uniform(0.5, 1.5, cout).astype(np.float32),
+                 mean=rng.normal(0, 0.1, cout).astype(np.float32), var=rng.uniform(0.5, 1.5, cout).astype(np.float32))
+        ps = [p["beta"], p["gamma"], p["mean"], p["var"]]
+    else:
+        p.update(bias=rng.normal(0, 0.1, cout).astype(np.float32))
+        ps = [p["bias"], None, None, None]
+    x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32) if cin != 3 else rng.random((B, H, W, 3), dtype=np.float32)
+    spec = dict(cin=cin, cout=cout, k=k, stride=stride, bn=bn)
+    ref = oracle.conv2d(x, p, spec)
+    res = None
+    if residual:
+        res = rng.normal(0, 1, ref.shape).astype(np.float32)
+        ref = ref + res
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    ptr = lambda a: a.ctypes.data if a is not None else None
+    _lib.check(L.yolo_conv_create(_lib.DTYPES[dtype], cin, cout, k, stride, int(bn), ptr(w), ptr(ps[0]), ptr(ps[1]),
+                                  ptr(ps[2]), ptr(ps[3]), ctypes.byref(h)))
+    try:
+        xd = _tensor.as_dev_f32(x)
+        rd = _tensor.as_dev_f32(res) if residual else None
+        out = _tensor.empty(ref.shape)
+        ws = _tensor.workspace(L.yolo_conv_workspace_bytes(h, B, H, W))
+        _lib.check(L.yolo_conv_forward(h, xd.data_ptr(), B, H, W, _tensor.ptr(rd), out.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), _tensor.stream_ptr()))
+        got = out.cpu().numpy()
+    finally:
+        L.yolo_conv_destroy(h)
+    return got, ref
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, bn, B, H, W, residual
+    (64, 32, 1, 1, True, 2, 16, 16, False),       # S2-like 1x1, BM=256 x BN=32 tile
+    (32, 64, 3, 1, True, 2, 16, 24, True),        # Cin=32: two taps per 128-byte K-step in bf16, residual
+    (32, 64, 3, 2, True, 1, 32, 32, False),       # stride-2 with explicit symmetric pad
+    (128, 256, 3, 1, True, 2, 13, 13, True),      # 128x128 tile, odd grid, M tail
+    (256, 512, 3, 2, True, 1, 26, 26, False),
+    (384, 128, 1, 1, True, 1, 20, 12, False),     # concat-sized Cin (not a power of two)
+    (512, 255, 1, 1, False, 2, 13, 13, False),    # detection head: bias, no activation, N=255
+    (3, 32, 3, 1, True, 2, 32, 32, False),        # stem
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d-%d_k%d_s%d" % c[:4])
+def test_conv_layer_fp32(torch_cuda, oracle, case):
+    got, ref = _conv_case(torch_cuda, oracle, "fp32", *case, seed=100)
+    ok, maxerr, rms = rel_rms_ok(got, ref, 1e-3)
+    assert ok, (maxerr, rms)
+    assert maxerr <= 2e-5 * max(rms, 1.0) * 10, (maxerr, rms)      # exact-f32 MFMA: really ~1e-6
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d-%d_k%d_s%d" % c[:4])
+def test_conv_layer_bf16(torch_cuda, oracle, case):
+    got, ref = _conv_case(torch_cuda, oracle, "bf16", *case, seed=101)
+    ok, maxerr, rms = rel_rms_ok(got, ref, 4e-2)
+    assert ok, (maxerr, rms)
+
+
+def test_conv_rejects_bad_arguments(torch_cuda):
+    from yolo_amd import _lib
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    w = np.zeros((3, 3, 5, 8), np.float32)
+    b = np.zeros(8, np.float32)
+    rc = L.yolo_conv_create(0, 5, 8, 3, 1, 0, w.ctypes.data, b.ctypes.data, None, None, None, ctypes.byref(h))
+    assert rc == -2 and b"Cin=5" in L.yolo_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole conv stack
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [64, 96])
+def test_forward_fp32_vs_reference_golden(net_f32, size):
+    """G1 fixture = the reference's own PyTorch Darknet-53 on the same synthetic weights."""
+    g = load_golden("g1_convstack_%d.npz" % size)
+    fms = net_f32.forward(g["img"])
+    for got, key in zip(fms, ("fm1", "fm2", "fm3")):
+        assert tuple(got.shape) == g[key].shape
+        ok, maxerr, rms = rel_rms_ok(got.cpu().numpy(), g[key], 1e-3)
+        assert ok, (key, maxerr, rms)
+
+
+def test_forward_fp32_416_batch2_vs_oracle(net_f32, oracle, oracle_params):
+    img = np.random.default_rng(1).random((2, 416, 416, 3), dtype=np.float32)
+    ref = oracle.forward(oracle_params, img)
+    got = net_f32.forward(img)
+    assert net_f32.img_size == (416, 416)
+    for a, b in zip(got, ref):
+        ok, maxerr, rms = rel_rms_ok(a.cpu().numpy(), b, 1e-3)
+        assert ok, (b.shape, maxerr, rms)
+
+
+def test_forward_fp32_rectangular_batch3(net_f32, oracle, oracle_params):
+    img = np.random.default_rng(3).random((3, 96, 160, 3), dtype=np.float32)
+    ref = oracle.forward(oracle_params, img)
+    got = net_f32.forward(img)
+    for a, b in zip(got, ref):
+        ok, maxerr, rms = rel_rms_ok(a.cpu().numpy(), b, 1e-3)
+        assert ok, (b.shape, maxerr, rms)
+
+
+def test_forward_bf16_vs_oracle(net_bf16, oracle, oracle_params):
+    """bf16 storage + bf16 MFMA inputs, f32 accumulate, 75 layers deep: stated tolerance
+    max |a-b| <= 1e-1*(|b| + rms(b)) and rms(a-b) <= 3e-2*rms(b)."""
+    img = np.random.default_rng(1).random((2, 416, 416, 3), dtype=np.float32)
+    ref = oracle.forward(oracle_params, img)
+    got = net_bf16.forward(img)
+    for a, b in zip(got, ref):
+        a = a.cpu().numpy()
+        ok, maxerr, rms = rel_rms_ok(a, b, 1e-1)
+        rmserr = float(np.sqrt(np.mean((a - b) ** 2)))
+        print("bf16 fm", b.shape, "max|err| %.4g rms(err) %.4g rms(ref) %.4g" % (maxerr, rmserr, rms))
+        assert ok, (b.shape, maxerr, rms)
+        assert rmserr <= 3e-2 * rms, (rmserr, rms)
+
+
+def test_forward_rejects_bad_shapes(net_f32):
+    with pytest.raises(ValueError):
+        net_f32.forward(np.zeros((1, 100, 96, 3), np.float32))
+    with pytest.raises(ValueError):
+        net_f32.forward(np.zeros((1, 96, 96, 4), np.float32))
+    with pytest.raises(ValueError):
+        net_f32.forward(np.zeros((1, 96, 96, 3), np.float32), is_training=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# decode
+# ---------------------------------------------------------------------------------------------
+def _rand_fms(rng, B, H, W, C, scale=1.5):
+    return [rng.normal(0, scale, (B, H // r, W // r, 3 * (5 + C))).astype(np.float32) for r in (32, 16, 8)]
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 416, 416, 80), (1, 608, 608, 80), (3, 96, 160, 20)])
+def test_decode_vs_oracle(torch_cuda, oracle, B, H, W, C):
+    from yolo_amd.model import yolov3
+    rng = np.random.default_rng(5)
+    fms = _rand_fms(rng, B, H, W, C)
+    fms[0][0, 0, 0, 2] = 12.0       # exp clip high
+    fms[0][0, 0, 0, 3] = -40.0      # exp clip low
+    m = yolov3(C, oracle.YOLO_ANCHORS)
+    m.img_size = (H, W)
+    boxes, confs, probs, scores = m.predict(fms, return_scores=True)
+    rb, rc, rp = oracle.predict(fms, oracle.YOLO_ANCHORS, (H, W), C)
+    n = 3 * sum((H // r) * (W // r) for r in (32, 16, 8))
+    assert tuple(boxes.shape) == (B, n, 4) and tuple(confs.shape) == (B, n, 1) and tuple(probs.shape) == (B, n, C)
+    np.testing.assert_allclose(boxes.cpu().numpy(), rb, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(confs.cpu().numpy(), rc, rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(probs.cpu().numpy(), rp, rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(scores.cpu().numpy(), rc * rp, rtol=1e-3, atol=1e-6)
+    b2, c2, p2 = m.predict(fms)
+    assert torch_cuda.equal(b2, boxes) and torch_cuda.equal(c2, confs) and torch_cuda.equal(p2, probs)
+
+
+def test_decode_vs_reference_golden(torch_cuda, oracle):
+    """G2: reference predict_transform output (xywh) for the fixture feature maps."""
+    from yolo_amd.model import yolov3
+    g = load_golden("g1_convstack_96.npz")
+    m = yolov3(80, oracle.YOLO_ANCHORS)
+    m.img_size = (96, 96)
+    boxes, confs, probs = m.predict([g["fm1"], g["fm2"], g["fm3"]])
+    det = g["det"][0]
+    cx, cy, w, h = det[:, 0], det[:, 1], det[:, 2], det[:, 3]
+    ref = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    np.testing.assert_allclose(boxes[0].cpu().numpy(), ref, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(confs[0, :, 0].cpu().numpy(), det[:, 4], atol=1e-6)
+    np.testing.assert_allclose(probs[0].cpu().numpy(), det[:, 5:], atol=1e-6)
+
+
+def test_reorg_layer_vs_oracle(torch_cuda, oracle):
+    from yolo_amd.model import yolov3
+    rng = np.random.default_rng(6)
+    fm = rng.normal(0, 1.5, (2, 6, 10, 255)).astype(np.float32)
+    m = yolov3(80, oracle.YOLO_ANCHORS)
+    m.img_size = (96, 160)
+    xy, boxes, cl, pl = m.reorg_layer(fm, oracle.YOLO_ANCHORS[3:6])
+    rxy, rb, rcl, rpl = oracle.reorg_layer(fm, oracle.YOLO_ANCHORS[3:6], (96, 160))
+    np.testing.assert_array_equal(xy.cpu().numpy(), rxy)
+    np.testing.assert_allclose(boxes.cpu().numpy(), rb, rtol=1e-3, atol=1e-3)
+    np.testing.assert_array_equal(cl.cpu().numpy(), rcl)
+    np.testing.assert_array_equal(pl.cpu().numpy(), rpl)
+
+
+# ---------------------------------------------------------------------------------------------
+# NMS: bit-exact
+# ---------------------------------------------------------------------------------------------
+def _boxes(rng, n, clustered=0, span=400.0, size=120.0, jitter=6.0):
+    if clustered:
+        xy = rng.random((clustered, 2)) * span
+        wh = rng.random((clustered, 2)) * size + 1
+        base = np.concatenate([xy, xy + wh], 1)
+        return (base[rng.integers(0, clustered, n)] + rng.normal(0, jitter, (n, 4))).astype(np.float32)
+    xy = rng.random((n, 2)) * span
+    wh = rng.random((n, 2)) * size + 1
+    return np.concatenate([xy, xy + wh], 1).astype(np.float32)
+
+
+def _check_gpu_nms(oracle, boxes, scores, C, max_boxes, st, it):
+    from yolo_amd.utils import nms_utils
+    rb, rs, rl, ri = oracle.gpu_nms(boxes, scores, C, max_boxes, st, it, return_indices=True)
+    ob, osc, ol, oi, oc = nms_utils.gpu_nms_batched(boxes.reshape(1, -1, 4), scores.reshape(1, -1, C), C, max_boxes, st, it)
+    m = int(oc[0])
+    assert m == len(ri), (m, len(ri))
+    np.testing.assert_array_equal(oi[0, :m].cpu().numpy(), ri)          # keep-indices, bit-exact
+    np.testing.assert_array_equal(ol[0, :m].cpu().numpy(), rl)
+    np.testing.assert_array_equal(ob[0, :m].cpu().numpy(), rb)
+    np.testing.assert_array_equal(osc[0, :m].cpu().numpy(), rs)
+    gb, gs, gl = nms_utils.gpu_nms(boxes, scores, C, max_boxes, st, it)
+    np.testing.assert_array_equal(gb.cpu().numpy(), rb)
+    np.testing.assert_array_equal(gs.cpu().numpy(), rs)
+    np.testing.assert_array_equal(gl.cpu().numpy(), rl)
+    assert gl.cpu().numpy().dtype == np.int32
+    return m
+
+
+@pytest.mark.parametrize("n,C,clustered,mb,st,it", [
+    (200, 3, 0, 50, 0.5, 0.5),
+    (1500, 5, 10, 20, 0.3, 0.45),
+    (10647, 80, 40, 50, 0.5, 0.5),       # config-2 shape
+    (10647, 80, 40, 30, 0.4, 0.5),       # test_single_image.py:39 thresholds
+    (3000, 2, 8, 7, 0.0, 0.6),           # k = n > 2048: best-alive path, max_boxes cut
+    (5000, 3, 3, 200, 0.05, 0.3),        # long suppression chains, candidates exhausted before max_boxes
+    (64, 1, 0, 50, 0.0, 0.5), (65, 1, 2, 50, 0.0, 0.5), (1, 1, 0, 50, 0.0, 0.5),
+])
+def test_gpu_nms_bit_exact(torch_cuda, oracle, n, C, clustered, mb, st, it):
+    rng = np.random.default_rng(n + C)
+    boxes = _boxes(rng, n, clustered)
+    scores = rng.random((n, C)).astype(np.float32)
+    _check_gpu_nms(oracle, boxes[None], scores[None], C, mb, st, it)
+
+
+def test_gpu_nms_ties_degenerate_and_empty(torch_cuda, oracle):
+    from yolo_amd.utils import nms_utils
+    rng = np.random.default_rng(77)
+    n, C = 4000, 4
+    boxes = _boxes(rng, n, 12)
+    boxes[::9, 2:] = boxes[::9, :2]                       # zero-area: never suppress / suppressed
+    boxes[4::17] = boxes[4::17][:, [2, 3, 0, 1]]          # flipped corners (TF normalises with min/max)
+    scores = (np.round(rng.random((n, C)) * 16) / 16).astype(np.float32)     # massive exact ties
+    scores[:, 2] = 0.0                                    # empty class in the middle
+    scores[5, 3] = -0.0
+    m = _check_gpu_nms(oracle, boxes[None], scores[None], C, 60, 0.25, 0.5)
+    assert m > 0
+    # nothing passes -> empty arrays with the reference's shapes (gpu) / None triple (cpu)
+    gb, gs, gl = nms_utils.gpu_nms(boxes[None], scores[None] * 0.1, C, 50, 0.9, 0.5)
+    assert tuple(gb.shape) == (0, 4) and tuple(gs.shape) == (0,) and tuple(gl.shape) == (0,)
+    assert nms_utils.cpu_nms(boxes[None], scores[None] * 0.1, C, 50, 0.9, 0.5) == (None, None, None)
+
+
+def test_gpu_nms_batched_equals_per_image(torch_cuda, oracle):
+    from yolo_amd.utils import nms_utils
+    rng = np.random.default_rng(8)
+    B, n, C = 4, 2500, 6
+    boxes = np.stack([_boxes(rng, n, 10) for _ in range(B)])
+    scores = rng.random((B, n, C)).astype(np.float32) ** 2
+    ob, osc, ol, oi, oc = nms_utils.gpu_nms_batched(boxes, scores, C, 25, 0.3, 0.5)
+    for i in range(B):
+        rb, rs, rl, ri = oracle.gpu_nms(boxes[i], scores[i], C, 25, 0.3, 0.5, return_indices=True)
+        m = int(oc[i])
+        assert m == len(ri)
+        np.testing.assert_array_equal(oi[i, :m].cpu().numpy(), ri)
+        np.testing.assert_array_equal(ob[i, :m].cpu().numpy(), rb)
+        np.testing.assert_array_equal(osc[i, :m].cpu().numpy(), rs)
+        np.testing.assert_array_equal(ol[i, :m].cpu().numpy(), rl)
+
+
+def test_gpu_nms_flattens_batch_like_reference(torch_cuda, oracle):
+    """nms_utils.py:20-21: with N > 1 the reference merges the images; the drop-in keeps that."""
+    from yolo_amd.utils import nms_utils
+    rng = np.random.default_rng(9)
+    boxes = _boxes(rng, 600, 6).reshape(2, 300, 4)
+    scores = rng.random((2, 300, 3)).astype(np.float32)
+    rb, rs, rl = oracle.gpu_nms(boxes, scores, 3, 10, 0.4, 0.5)
+    gb, gs, gl = nms_utils.gpu_nms(boxes, scores, 3, 10, 0.4, 0.5)
+    np.testing.assert_array_equal(gb.cpu().numpy(), rb)
+    np.testing.assert_array_equal(gs.cpu().numpy(), rs)
+    np.testing.assert_array_equal(gl.cpu().numpy(), rl)
+
+
+def test_cpu_nms_and_py_nms_vs_reference_golden(torch_cuda):
+    """G3: outputs of the reference's own numpy cpu_nms / py_nms (bit-exact)."""
+    from yolo_amd.utils import nms_utils
+    g = load_golden("g3_cpu_nms.npz")
+    names = sorted({k.split("/")[0] for k in g.files})
+    for name in names:
+        d = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+        if name.startswith("py_nms"):
+            keep = nms_utils.py_nms(d["boxes"], d["scores"], int(d["max_boxes"]), float(d["iou_thresh"]))
+            np.testing.assert_array_equal(np.asarray(keep), d["keep"], err_msg=name)
+            continue
+        b, s, l = nms_utils.cpu_nms(d["boxes"], d["scores"], int(d["C"]), int(d["max_boxes"]),
+                                    float(d["score_thresh"]), float(d["iou_thresh"]))
+        if bool(d["none"]):
+            assert b is None and s is None and l is None, name
+            continue
+        np.testing.assert_array_equal(b, d["out_boxes"], err_msg=name)
+        np.testing.assert_array_equal(s, d["out_scores"], err_msg=name)
+        np.testing.assert_array_equal(l, d["out_labels"], err_msg=name)
+        assert l.dtype == np.int32 and s.dtype == np.float32
+
+
+def test_nms_stress_608_properties(torch_cuda, oracle):
+    """Config 5 shape (22743 x 80, score_thresh 0.001) on one image: oracle equality on a class subset
+    plus size-independent properties (idempotence, score order, pairwise IoU <= thresh)."""
+    from yolo_amd.utils import nms_utils
+    rng = np.random.default_rng(55)
+    fms = _rand_fms(rng, 1, 608, 608, 80, 1.0)
+    boxes, confs, probs = oracle.predict(fms, oracle.YOLO_ANCHORS, (608, 608))
+    scores = (confs * probs).astype(np.float32)
+    ob, osc, ol, oi, oc = nms_utils.gpu_nms_batched(boxes, scores, 80, 50, 0.001, 0.5)
+    m = int(oc[0])
+    ob, osc, ol, oi = [t[0, :m].cpu().numpy() for t in (ob, osc, ol, oi)]
+    assert m == 80 * 50
+    for c in (0, 17, 79):
+        ref = oracle.class_nms_c(boxes[0], scores[0], c, 50, 0.001, 0.5, 0)
+        np.testing.assert_array_equal(oi[ol == c], ref)
+    for c in range(80):
+        s = osc[ol == c]
+        assert np.all(s[:-1] >= s[1:])
+    # idempotence: NMS of the kept boxes keeps them all
+    for c in (3, 40):
+        kb, ks = ob[ol == c], osc[ol == c]
+        again = oracle.tf_non_max_suppression(kb, ks, 50, 0.5)
+        np.testing.assert_array_equal(again, np.arange(len(kb)))

@@ -1,0 +1,57 @@
+// Shared host-side helpers for libyolo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/yolo_hip.h"
+
+namespace yolo {
+
+void set_error(const char* fmt, ...);
+
+#define YOLO_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            yolo::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return YOLO_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define YOLO_REQUIRE(cond, code, ...)       \
+    do {                                    \
+        if (!(cond)) {                      \
+            yolo::set_error(__VA_ARGS__);   \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- conv layer launch description (device pointers) ------------------------------------
+struct ConvLaunch {
+    const void* in;        // activations, element type = net dtype (stem: always f32)
+    const void* w;         // packed weights [Npad][Kpad] (k = (ky,kx,ci)), BN folded
+    const float* bias;     // [Npad] folded bias
+    void* out;
+    const void* res;       // residual or nullptr (same dtype/geometry as out)
+    const void* zero;      // >= 16 zero bytes (source of padded taps)
+    int B, H, W, Cin;      // input geometry
+    int Ho, Wo, Cout;      // conv output geometry (before the optional 2x upsample scatter)
+    int ksize, stride, pad;
+    int in_ld, in_coff;    // elements per input pixel row / first channel
+    int out_ld, out_coff;
+    int res_ld, res_coff;
+    int kpad_bytes;        // bytes per packed weight row (multiple of 128)
+    int leaky;             // 1: 0.55x + 0.45|x| ; 0: linear
+    int upsample;          // 1: write every output pixel to the 2x2 block of a [B,2Ho,2Wo] tensor
+    int out_f32;           // 1: out is float32 regardless of dtype (detection heads), scalar stores
+};
+
+int launch_conv_igemm(int dtype, const ConvLaunch& p, hipStream_t stream);
+int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream);   // Cin = 3, 3x3 s1, f32 in
+int launch_cast_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t stream);
+int launch_cast_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t stream);
+
+}  // namespace yolo

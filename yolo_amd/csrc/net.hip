@@ -1,0 +1,446 @@
+// Host side of libyolo_hip.so: weight ingestion (Darknet order, BN folding, K-major packing),
+// the static execution plan of yolov3.forward (reference yolo_v3/model.py:21-67 +
+// yolo_v3/utils/layer_utils.py:23-72) and the C-ABI entry points for the conv stack.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+
+namespace yolo {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// ---- one conv layer's device-resident parameters -------------------------------------------------
+struct ConvParams {
+    int cin = 0, cout = 0, k = 0, stride = 1, bn = 1;
+    int dtype = YOLO_DTYPE_F32;
+    bool stem = false;          // Cin == 3 direct kernel, weights packed [27][Cout] f32
+    int kpad_bytes = 0, npad = 0;
+    void* w = nullptr;
+    float* bias = nullptr;
+    ~ConvParams() {
+        if (w) (void)hipFree(w);
+        if (bias) (void)hipFree(bias);
+    }
+};
+
+// w_at(n, ci, ky, kx) abstracts the host layout (Darknet OIHW stream or TF HWIO variable).
+template <class WAt>
+static int pack_conv(ConvParams& L, WAt w_at, const float* p0, const float* p1, const float* p2, const float* p3) {
+    const int co = L.cout, ci = L.cin, k = L.k;
+    std::vector<float> scale(co), bias(co);
+    for (int n = 0; n < co; ++n) {
+        if (L.bn) {
+            // inference BN (model.py:24-30, eps 1e-5): y = (x - mean) * gamma / sqrt(var + eps) + beta
+            const float beta = p0[n], gamma = p1[n], mean = p2[n], var = p3[n];
+            const float s = gamma / std::sqrt(var + 1e-5f);
+            scale[n] = s;
+            bias[n] = beta - mean * s;
+        } else {
+            scale[n] = 1.0f;
+            bias[n] = p0[n];
+        }
+    }
+    L.stem = (ci == 3);
+    const int sz = L.dtype == YOLO_DTYPE_BF16 ? 2 : 4;
+    size_t wbytes;
+    std::vector<char> host;
+    if (L.stem) {
+        L.npad = co;
+        L.kpad_bytes = 0;
+        wbytes = (size_t)k * k * ci * co * 4;
+        host.assign(wbytes, 0);
+        float* hw = (float*)host.data();
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+                for (int c = 0; c < ci; ++c)
+                    for (int n = 0; n < co; ++n) hw[((ky * k + kx) * ci + c) * co + n] = w_at(n, c, ky, kx) * scale[n];
+    } else {
+        L.npad = (int)align_up((size_t)co, 128);
+        L.kpad_bytes = (int)align_up((size_t)k * k * ci * sz, 128);
+        wbytes = (size_t)L.npad * L.kpad_bytes;
+        host.assign(wbytes, 0);
+        for (int n = 0; n < co; ++n) {
+            char* rowp = host.data() + (size_t)n * L.kpad_bytes;
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx)
+                    for (int c = 0; c < ci; ++c) {
+                        const float v = w_at(n, c, ky, kx) * scale[n];
+                        const size_t kidx = (size_t)(ky * k + kx) * ci + c;
+                        if (sz == 2) ((uint16_t*)rowp)[kidx] = f32_to_bf16_rne(v);
+                        else ((float*)rowp)[kidx] = v;
+                    }
+        }
+    }
+    std::vector<float> bias_pad(L.npad, 0.f);
+    memcpy(bias_pad.data(), bias.data(), (size_t)co * 4);
+    YOLO_HIP_CHECK(hipMalloc(&L.w, wbytes));
+    YOLO_HIP_CHECK(hipMalloc((void**)&L.bias, (size_t)L.npad * 4));
+    YOLO_HIP_CHECK(hipMemcpy(L.w, host.data(), wbytes, hipMemcpyHostToDevice));
+    YOLO_HIP_CHECK(hipMemcpy(L.bias, bias_pad.data(), (size_t)L.npad * 4, hipMemcpyHostToDevice));
+    return YOLO_OK;
+}
+
+static int run_conv(const ConvParams& L, ConvLaunch p, hipStream_t stream) {
+    p.w = L.w;
+    p.bias = L.bias;
+    p.Cin = L.cin;
+    p.Cout = L.cout;
+    p.ksize = L.k;
+    p.stride = L.stride;
+    p.pad = (L.k - 1) / 2;          // layer_utils.py:11-20: SAME (s1) / explicit symmetric pad + VALID (s2)
+    p.kpad_bytes = L.kpad_bytes;
+    p.Ho = (p.H + 2 * p.pad - L.k) / L.stride + 1;
+    p.Wo = (p.W + 2 * p.pad - L.k) / L.stride + 1;
+    p.leaky = L.bn ? 1 : 0;         // model.py:32-36 vs :42-44
+    return L.stem ? launch_stem(L.dtype, p, stream) : launch_conv_igemm(L.dtype, p, stream);
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+// ---- architecture -------------------------------------------------------------------------------
+struct Spec { int cin, cout, k, stride, bn; };
+
+static std::vector<Spec> yolov3_specs(int class_num) {
+    std::vector<Spec> v;
+    auto conv = [&](int ci, int co, int k, int s = 1, int bn = 1) { v.push_back({ci, co, k, s, bn}); return co; };
+    auto res = [&](int c, int f) { conv(c, f, 1); conv(f, 2 * f, 3); return 2 * f; };      // layer_utils.py:24-29
+    int c = conv(3, 32, 3);                                                               // :31
+    c = conv(c, 64, 3, 2);                                                                // :32
+    c = res(c, 32);
+    c = conv(c, 128, 3, 2);
+    for (int i = 0; i < 2; ++i) c = res(c, 64);
+    c = conv(c, 256, 3, 2);
+    for (int i = 0; i < 8; ++i) c = res(c, 128);
+    c = conv(c, 512, 3, 2);
+    for (int i = 0; i < 8; ++i) c = res(c, 256);
+    c = conv(c, 1024, 3, 2);
+    for (int i = 0; i < 4; ++i) c = res(c, 512);
+    auto block = [&](int ci, int f) {                                                     // layer_utils.py:56-65
+        conv(ci, f, 1); conv(f, 2 * f, 3); conv(2 * f, f, 1); conv(f, 2 * f, 3); conv(2 * f, f, 1); conv(f, 2 * f, 3);
+    };
+    const int nout = 3 * (5 + class_num);
+    block(1024, 512); conv(1024, nout, 1, 1, 0); conv(512, 256, 1);                        // model.py:41-47
+    block(768, 256); conv(512, nout, 1, 1, 0); conv(256, 128, 1);                          // model.py:49-57
+    block(384, 128); conv(256, nout, 1, 1, 0);                                             // model.py:59-64
+    return v;
+}
+
+// One step of the static plan.  Tensor ids index Plan::tens; -1 = none, -2/-3/-4 = fm1/fm2/fm3, -5 = image.
+struct Step {
+    int layer;
+    int in, out, res;
+    int in_coff, out_coff;
+    int upsample;
+};
+struct Tens { int h, w, ld; size_t bytes; int first, last; size_t offset; };
+struct Plan { std::vector<Step> steps; std::vector<Tens> tens; size_t ws_bytes = 0; };
+
+struct YoloNet {
+    int class_num = 0, dtype = 0;
+    std::vector<Spec> specs;
+    std::vector<std::unique_ptr<ConvParams>> layers;
+    std::map<std::tuple<int, int, int>, Plan> plans;
+    std::mutex mu;
+};
+struct YoloConv { ConvParams p; };
+
+static Plan build_plan(const YoloNet& net, int B, int H, int W) {
+    Plan P;
+    const int sz = net.dtype == YOLO_DTYPE_BF16 ? 2 : 4;
+    auto tensor = [&](int h, int w, int ld) {
+        P.tens.push_back({h, w, ld, align_up((size_t)B * h * w * ld * sz, 256), -1, -1, 0});
+        return (int)P.tens.size() - 1;
+    };
+    int li = 0;
+    // conv into a fresh tensor (or an existing one at a channel offset)
+    auto conv = [&](int in, int in_coff, int h_in, int w_in, int res = -1, int out = -1, int out_coff = 0, int ups = 0) {
+        const Spec& s = net.specs[li];
+        const int ho = h_in / s.stride, wo = w_in / s.stride;
+        if (out == -1) out = tensor(ups ? 2 * ho : ho, ups ? 2 * wo : wo, s.cout);
+        P.steps.push_back({li, in, out, res, in_coff, out_coff, ups});
+        ++li;
+        return out;
+    };
+    int h = H, w = W;
+    int x = conv(-5, 0, h, w);                               // stem
+    auto down = [&](int in, int coff) { int o = conv(in, coff, h, w); h /= 2; w /= 2; return o; };
+    auto res_block = [&](int in, int coff, int out = -1, int out_coff = 0) {
+        int t = conv(in, coff, h, w);
+        return conv(t, 0, h, w, in, out, out_coff);      // residual = block input (always a dense tensor here)
+    };
+    x = down(x, 0);
+    x = res_block(x, 0);
+    x = down(x, 0);
+    for (int i = 0; i < 2; ++i) x = res_block(x, 0);
+    x = down(x, 0);
+    const int g3h = h, g3w = w;                              // stride-8 grid
+    const int concat2 = tensor(g3h, g3w, 128 + 256);         // [upsampled inter2 | route_1]   model.py:59
+    for (int i = 0; i < 7; ++i) x = res_block(x, 0);
+    x = res_block(x, 0, concat2, 128);                       // route_1 lives inside concat2
+    int xc = 128;
+    x = down(x, xc);
+    const int g2h = h, g2w = w;
+    const int concat1 = tensor(g2h, g2w, 256 + 512);         // [upsampled inter1 | route_2]   model.py:49
+    for (int i = 0; i < 7; ++i) x = res_block(x, 0);
+    x = res_block(x, 0, concat1, 256);                       // route_2 lives inside concat1
+    xc = 256;
+    x = down(x, xc);
+    for (int i = 0; i < 4; ++i) x = res_block(x, 0);         // route_3
+    auto yolo_block = [&](int in, int& route) {              // layer_utils.py:56-65
+        int t = in;
+        for (int i = 0; i < 5; ++i) t = conv(t, 0, h, w);
+        route = t;
+        return conv(t, 0, h, w);
+    };
+    int inter1, inter2, dummy;
+    int net1 = yolo_block(x, inter1);
+    conv(net1, 0, h, w, -1, -2);                             // feature_map_1   model.py:42-44
+    conv(inter1, 0, h, w, -1, concat1, 0, 1);                // model.py:47-49 conv + upsample + concat
+    h = g2h; w = g2w;
+    int net2 = yolo_block(concat1, inter2);
+    conv(net2, 0, h, w, -1, -3);                             // feature_map_2
+    conv(inter2, 0, h, w, -1, concat2, 0, 1);                // model.py:57-59
+    h = g3h; w = g3w;
+    int net3 = yolo_block(concat2, dummy);
+    conv(net3, 0, h, w, -1, -4);                             // feature_map_3
+    // lifetimes -> offsets (first-fit over live intervals)
+    for (size_t s = 0; s < P.steps.size(); ++s) {
+        const Step& st = P.steps[s];
+        for (int id : {st.in, st.out, st.res})
+            if (id >= 0) {
+                if (P.tens[id].first < 0) P.tens[id].first = (int)s;
+                P.tens[id].last = (int)s;
+            }
+    }
+    std::vector<int> order(P.tens.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::vector<int> placed;
+    for (size_t s = 0; s < P.steps.size(); ++s)
+        for (size_t id = 0; id < P.tens.size(); ++id) {
+            Tens& t = P.tens[id];
+            if (t.first != (int)s) continue;
+            // concat buffers are created early (first written mid-backbone); plain first-fit
+            size_t off = 0;
+            bool moved = true;
+            while (moved) {
+                moved = false;
+                for (int o : placed) {
+                    const Tens& u = P.tens[o];
+                    if (u.last < t.first || u.first > t.last) continue;          // disjoint lifetimes
+                    if (off < u.offset + u.bytes && u.offset < off + t.bytes) { off = u.offset + u.bytes; moved = true; }
+                }
+            }
+            t.offset = off;
+            placed.push_back((int)id);
+            if (off + t.bytes > P.ws_bytes) P.ws_bytes = off + t.bytes;
+        }
+    return P;
+}
+
+static int get_plan(YoloNet* net, int B, int H, int W, const Plan** out) {
+    YOLO_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, YOLO_ERR_SHAPE,
+                 "forward: need B > 0 and H, W positive multiples of 32 (got B=%d, %dx%d)", B, H, W);
+    std::lock_guard<std::mutex> g(net->mu);
+    auto key = std::make_tuple(B, H, W);
+    auto it = net->plans.find(key);
+    if (it == net->plans.end()) it = net->plans.emplace(key, build_plan(*net, B, H, W)).first;
+    *out = &it->second;
+    return YOLO_OK;
+}
+
+extern "C" const char* yolo_last_error(void) { return g_err; }
+extern "C" int yolo_abi_version(void) { return 1; }
+
+extern "C" int yolo_net_create(int class_num, int dtype, const float* stream, size_t n_floats, YoloNet** out) {
+    YOLO_REQUIRE(stream && out, YOLO_ERR_ARG, "net_create: null pointer");
+    YOLO_REQUIRE(class_num > 0 && class_num <= 4096, YOLO_ERR_ARG, "net_create: class_num %d", class_num);
+    YOLO_REQUIRE(dtype == YOLO_DTYPE_F32 || dtype == YOLO_DTYPE_BF16, YOLO_ERR_ARG, "net_create: dtype %d", dtype);
+    std::unique_ptr<YoloNet> net(new YoloNet);
+    net->class_num = class_num;
+    net->dtype = dtype;
+    net->specs = yolov3_specs(class_num);
+    size_t need = 0;
+    for (const Spec& s : net->specs) need += (size_t)(s.bn ? 4 : 1) * s.cout + (size_t)s.cout * s.cin * s.k * s.k;
+    YOLO_REQUIRE(need == n_floats, YOLO_ERR_SHAPE, "net_create: weight stream has %zu floats, architecture needs %zu", n_floats, need);
+    const float* ptr = stream;
+    for (const Spec& s : net->specs) {
+        std::unique_ptr<ConvParams> L(new ConvParams);
+        L->cin = s.cin; L->cout = s.cout; L->k = s.k; L->stride = s.stride; L->bn = s.bn; L->dtype = dtype;
+        // misc_utils.py:59-95: [beta, gamma, mean, var] or [bias], then kernel [Cout, Cin, kh, kw]
+        const float *p0 = ptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+        if (s.bn) { p1 = ptr + s.cout; p2 = ptr + 2 * s.cout; p3 = ptr + 3 * s.cout; ptr += 4 * (size_t)s.cout; }
+        else ptr += s.cout;
+        const float* wk = ptr;
+        const int ci = s.cin, k = s.k;
+        int rc = pack_conv(*L, [=](int n, int c, int ky, int kx) { return wk[(((size_t)n * ci + c) * k + ky) * k + kx]; }, p0, p1, p2, p3);
+        if (rc != YOLO_OK) return rc;
+        ptr += (size_t)s.cout * s.cin * s.k * s.k;
+        net->layers.push_back(std::move(L));
+    }
+    *out = net.release();
+    return YOLO_OK;
+}
+
+extern "C" int yolo_net_destroy(YoloNet* net) {
+    delete net;
+    return YOLO_OK;
+}
+
+extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->layers.size() : 0; }
+
+extern "C" size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int W) {
+    if (!net) return 0;
+    const Plan* P = nullptr;
+    if (get_plan(const_cast<YoloNet*>(net), B, H, W, &P) != YOLO_OK) return 0;
+    return P->ws_bytes;
+}
+
+extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                                float* fm1, float* fm2, float* fm3, void* stream) {
+    YOLO_REQUIRE(net && images && workspace && fm1 && fm2 && fm3, YOLO_ERR_ARG, "forward: null pointer");
+    const Plan* P = nullptr;
+    int rc = get_plan(net, B, H, W, &P);
+    if (rc != YOLO_OK) return rc;
+    YOLO_REQUIRE(workspace_bytes >= P->ws_bytes, YOLO_ERR_WORKSPACE, "forward: workspace %zu < %zu bytes", workspace_bytes, P->ws_bytes);
+    YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "forward: workspace must be 256-byte aligned");
+    const int nout = 3 * (5 + net->class_num);
+    float* fms[3] = {fm1, fm2, fm3};
+    int h_in = H, w_in = W;
+    (void)h_in; (void)w_in;
+    for (const Step& st : P->steps) {
+        const ConvParams& L = *net->layers[st.layer];
+        ConvLaunch p;
+        memset(&p, 0, sizeof(p));
+        p.B = B;
+        if (st.in == -5) { p.in = images; p.H = H; p.W = W; p.in_ld = 3; p.in_coff = 0; }
+        else {
+            const Tens& t = P->tens[st.in];
+            p.in = (char*)workspace + t.offset; p.H = t.h; p.W = t.w; p.in_ld = t.ld; p.in_coff = st.in_coff;
+        }
+        if (st.out <= -2) { p.out = fms[-2 - st.out]; p.out_ld = nout; p.out_coff = 0; p.out_f32 = 1; }
+        else {
+            const Tens& t = P->tens[st.out];
+            p.out = (char*)workspace + t.offset; p.out_ld = t.ld; p.out_coff = st.out_coff;
+        }
+        if (st.res >= 0) {
+            const Tens& t = P->tens[st.res];
+            p.res = (char*)workspace + t.offset; p.res_ld = t.ld; p.res_coff = 0;
+        }
+        p.upsample = st.upsample;
+        rc = run_conv(L, p, (hipStream_t)stream);
+        if (rc != YOLO_OK) return rc;
+    }
+    return YOLO_OK;
+}
+
+// ---- single layer ---------------------------------------------------------------------------------
+extern "C" int yolo_conv_create(int dtype, int cin, int cout, int ksize, int stride, int bn, const float* w_hwio,
+                                const float* p0, const float* p1, const float* p2, const float* p3, YoloConv** out) {
+    YOLO_REQUIRE(w_hwio && p0 && out, YOLO_ERR_ARG, "conv_create: null pointer");
+    YOLO_REQUIRE(!bn || (p1 && p2 && p3), YOLO_ERR_ARG, "conv_create: bn needs beta, gamma, mean, var");
+    YOLO_REQUIRE(dtype == YOLO_DTYPE_F32 || dtype == YOLO_DTYPE_BF16, YOLO_ERR_ARG, "conv_create: dtype %d", dtype);
+    YOLO_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cin > 0 && cout > 0, YOLO_ERR_UNSUPPORTED,
+                 "conv_create: ksize %d stride %d", ksize, stride);
+    const int sz = dtype == YOLO_DTYPE_BF16 ? 2 : 4;
+    if (cin == 3)
+        YOLO_REQUIRE(ksize == 3 && stride == 1 && cout == 32, YOLO_ERR_UNSUPPORTED, "conv_create: Cin=3 only as the 3x3 s1 3->32 stem");
+    else
+        YOLO_REQUIRE((cin * sz) % 64 == 0 && (128 % (cin * sz) == 0 || (cin * sz) % 128 == 0), YOLO_ERR_SHAPE,
+                     "conv_create: Cin=%d unsupported (need Cin*sizeof a divisor or multiple of 128 bytes)", cin);
+    std::unique_ptr<YoloConv> c(new YoloConv);
+    ConvParams& L = c->p;
+    L.cin = cin; L.cout = cout; L.k = ksize; L.stride = stride; L.bn = bn; L.dtype = dtype;
+    int rc = pack_conv(L, [=](int n, int ci, int ky, int kx) { return w_hwio[(((size_t)ky * ksize + kx) * cin + ci) * cout + n]; },
+                       p0, p1, p2, p3);
+    if (rc != YOLO_OK) return rc;
+    *out = c.release();
+    return YOLO_OK;
+}
+
+extern "C" int yolo_conv_destroy(YoloConv* c) {
+    delete c;
+    return YOLO_OK;
+}
+
+static void conv_ws_layout(const ConvParams& L, int B, int H, int W, size_t* in_b, size_t* out_b, size_t* res_b) {
+    const int pad = (L.k - 1) / 2;
+    const int ho = (H + 2 * pad - L.k) / L.stride + 1, wo = (W + 2 * pad - L.k) / L.stride + 1;
+    const bool bf = L.dtype == YOLO_DTYPE_BF16;
+    const int cpad = (int)align_up((size_t)L.cout, 8);
+    *in_b = (bf && !L.stem) ? align_up((size_t)B * H * W * L.cin * 2, 256) : 0;
+    *out_b = (bf || cpad != L.cout) ? align_up((size_t)B * ho * wo * cpad * (bf ? 2 : 4), 256) : 0;
+    *res_b = bf ? align_up((size_t)B * ho * wo * L.cout * 2, 256) : 0;
+}
+
+extern "C" size_t yolo_conv_workspace_bytes(const YoloConv* c, int B, int H, int W) {
+    if (!c || B <= 0 || H <= 0 || W <= 0) return 0;
+    size_t a, b, r;
+    conv_ws_layout(c->p, B, H, W, &a, &b, &r);
+    return a + b + r + 256;
+}
+
+extern "C" int yolo_conv_forward(YoloConv* c, const float* in, int B, int H, int W, const float* residual, float* out,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    YOLO_REQUIRE(c && in && out, YOLO_ERR_ARG, "conv_forward: null pointer");
+    YOLO_REQUIRE(B > 0 && H > 0 && W > 0, YOLO_ERR_ARG, "conv_forward: non-positive shape");
+    const ConvParams& L = c->p;
+    if (L.stride == 2) YOLO_REQUIRE(H % 2 == 0 && W % 2 == 0, YOLO_ERR_SHAPE, "conv_forward: stride-2 conv needs even H, W");
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t in_b, out_b, res_b;
+    conv_ws_layout(L, B, H, W, &in_b, &out_b, &res_b);
+    YOLO_REQUIRE(in_b + out_b + res_b == 0 || (workspace && workspace_bytes >= in_b + out_b + res_b), YOLO_ERR_WORKSPACE,
+                 "conv_forward: workspace %zu < %zu bytes", workspace_bytes, in_b + out_b + res_b);
+    YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "conv_forward: workspace must be 256-byte aligned");
+    const bool bf = L.dtype == YOLO_DTYPE_BF16;
+    const int pad = (L.k - 1) / 2;
+    const int ho = (H + 2 * pad - L.k) / L.stride + 1, wo = (W + 2 * pad - L.k) / L.stride + 1;
+    char* ws = (char*)workspace;
+    ConvLaunch p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.in_ld = L.cin;
+    int rc;
+    if (in_b) {
+        rc = launch_cast_f32_to_bf16(in, ws, (size_t)B * H * W * L.cin, stream);
+        if (rc != YOLO_OK) return rc;
+        p.in = ws;
+    } else p.in = in;
+    const bool head = (L.cout % 8) != 0;          // detection conv: direct f32 scalar stores
+    if (head) { p.out = out; p.out_ld = L.cout; p.out_f32 = 1; }
+    else if (bf) { p.out = ws + in_b; p.out_ld = L.cout; }
+    else { p.out = out; p.out_ld = L.cout; }
+    if (residual) {
+        YOLO_REQUIRE(!head, YOLO_ERR_UNSUPPORTED, "conv_forward: residual on a detection conv");
+        if (bf) {
+            rc = launch_cast_f32_to_bf16(residual, ws + in_b + out_b, (size_t)B * ho * wo * L.cout, stream);
+            if (rc != YOLO_OK) return rc;
+            p.res = ws + in_b + out_b;
+        } else p.res = residual;
+        p.res_ld = L.cout;
+    }
+    rc = run_conv(L, p, stream);
+    if (rc != YOLO_OK) return rc;
+    if (bf && !head) return launch_cast_bf16_to_f32(ws + in_b, out, (size_t)B * ho * wo * L.cout, stream);
+    return YOLO_OK;
+}

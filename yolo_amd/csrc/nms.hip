@@ -1,0 +1,329 @@
+// Per-class NMS for gfx950.  Replaces gpu_nms (reference yolo_v3/utils/nms_utils.py:7-37: score mask +
+// tf.boolean_mask + tf.image.non_max_suppression + tf.gather per class) and, in YOLO_NMS_PY mode,
+// cpu_nms / py_nms (nms_utils.py:40-90).  Integer/compare work plus IEEE single ops only: results are
+// bit-identical to the CPU oracle (every float op is a single correctly rounded +,-,*,/; this TU is
+// built with -ffp-contract=off and uses the _rn intrinsics).
+//
+// Three kernels per call:
+//  1. nms_compact : streams scores [B,n,C] once (HBM-bound), tile -> LDS, one wave per class column,
+//                   ballot + prefix compaction, ONE atomic per (tile, class) -> candidate keys
+//                   key = (~sortable(score) << 32) | index   (TF mode; PY mode stores ~index so that
+//                   equal scores come out in descending index order like argsort()[::-1]).
+//  2. nms_select  : one workgroup per (image, class).
+//        k <= 2048 : keys sorted in LDS (bitonic), then wave 0 walks the sorted list 64 candidates
+//                    at a time: test against the selected boxes (LDS), build the 64x64 IoU bitmask
+//                    of the chunk (one 64-bit word per lane), run the LDS-resident suppression scan,
+//                    append the survivors; stops at max_boxes.
+//        k  > 2048 : (eval-mode stress, score_thresh 0.001) repeated "best alive candidate" passes:
+//                    every pass kills what the last selected box suppresses and min-reduces the
+//                    surviving keys; at most max_boxes passes, no sort.
+//  3. nms_gather  : per image, prefix over class counts -> class-ordered dense output rows.
+#include "common.h"
+
+namespace yolo {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned long long u64;
+
+constexpr int kSortCap = 2048;   // candidates per (image, class) handled by the LDS sort path
+constexpr int kSelCap = 1024;    // max_boxes limit (selected boxes are kept in LDS)
+constexpr int kTileJ = 128;      // boxes per compaction tile
+constexpr int kTileC = 96;       // classes per compaction tile (LDS: 128 x 97 floats)
+constexpr u64 kDead = ~0ull;
+
+// ---- exact-arithmetic overlap tests ------------------------------------------------------------
+// TF 1.x non_max_suppression_op.cc, IOUGreaterThanThreshold (boxes are read as pairs (0,2), (1,3)).
+__device__ __forceinline__ bool tf_suppresses(const f32x4 a, const f32x4 b, float thr) {
+    const float a_lo0 = fminf(a[0], a[2]), a_hi0 = fmaxf(a[0], a[2]);
+    const float a_lo1 = fminf(a[1], a[3]), a_hi1 = fmaxf(a[1], a[3]);
+    const float b_lo0 = fminf(b[0], b[2]), b_hi0 = fmaxf(b[0], b[2]);
+    const float b_lo1 = fminf(b[1], b[3]), b_hi1 = fmaxf(b[1], b[3]);
+    const float area_a = __fmul_rn(__fsub_rn(a_hi0, a_lo0), __fsub_rn(a_hi1, a_lo1));
+    const float area_b = __fmul_rn(__fsub_rn(b_hi0, b_lo0), __fsub_rn(b_hi1, b_lo1));
+    if (area_a <= 0.0f || area_b <= 0.0f) return false;
+    const float d0 = fmaxf(__fsub_rn(fminf(a_hi0, b_hi0), fmaxf(a_lo0, b_lo0)), 0.0f);
+    const float d1 = fmaxf(__fsub_rn(fminf(a_hi1, b_hi1), fmaxf(a_lo1, b_lo1)), 0.0f);
+    const float inter = __fmul_rn(d0, d1);
+    const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_a, area_b), inter));
+    return iou > thr;
+}
+
+// nms_utils.py:48,54-62 (areas without min/max, +1 on w/h, keep iff ovr <= thr).
+__device__ __forceinline__ bool py_drops(const f32x4 s, const f32x4 b, float thr) {
+    const float area_s = __fmul_rn(__fsub_rn(s[2], s[0]), __fsub_rn(s[3], s[1]));
+    const float area_b = __fmul_rn(__fsub_rn(b[2], b[0]), __fsub_rn(b[3], b[1]));
+    const float xx1 = fmaxf(s[0], b[0]), yy1 = fmaxf(s[1], b[1]);
+    const float xx2 = fminf(s[2], b[2]), yy2 = fminf(s[3], b[3]);
+    const float w = fmaxf(0.0f, __fadd_rn(__fsub_rn(xx2, xx1), 1.0f));
+    const float h = fmaxf(0.0f, __fadd_rn(__fsub_rn(yy2, yy1), 1.0f));
+    const float inter = __fmul_rn(w, h);
+    const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_s, area_b), inter));
+    return !(ovr <= thr);
+}
+
+template <int MODE>
+__device__ __forceinline__ bool suppresses(const f32x4 sel, const f32x4 b, float thr) {
+    return MODE == YOLO_NMS_TF ? tf_suppresses(sel, b, thr) : py_drops(sel, b, thr);
+}
+
+template <int MODE>
+__device__ __forceinline__ u64 make_key(float score, unsigned idx) {
+    const unsigned bits = __float_as_uint(score + 0.0f);                 // -0 -> +0
+    const unsigned u = bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u);  // monotone in the float order
+    return ((u64)(~u) << 32) | (MODE == YOLO_NMS_TF ? idx : ~idx);
+}
+template <int MODE>
+__device__ __forceinline__ unsigned key_index(u64 key) {
+    const unsigned lo = (unsigned)key;
+    return MODE == YOLO_NMS_TF ? lo : ~lo;
+}
+
+// ---- 1. compaction -----------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restrict__ scores, int n, int C, float thr,
+                                                          int* __restrict__ cand_count, u64* __restrict__ cand_keys) {
+    __shared__ float tile[kTileJ * (kTileC + 1)];
+    const int b = blockIdx.y;
+    const int j0 = blockIdx.x * kTileJ;
+    const int nj = min(kTileJ, n - j0);
+    const int c0 = blockIdx.z * kTileC;
+    const int cw = min(kTileC, C - c0);
+    constexpr int ldt = kTileC + 1;              // odd stride: column reads are bank-conflict free
+    const float* src = scores + ((long long)b * n + j0) * C + c0;
+    for (int e = threadIdx.x; e < nj * cw; e += 256) {
+        const int j = e / cw;
+        const int c = e - j * cw;
+        tile[j * ldt + c] = src[(long long)j * C + c];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int cl = wave; cl < cw; cl += 4) {
+        const int c = c0 + cl;
+        int* cnt = cand_count + (long long)b * C + c;
+        u64* keys = cand_keys + ((long long)b * C + c) * n;
+#pragma unroll
+        for (int h = 0; h < kTileJ / 64; ++h) {
+            const int j = h * 64 + lane;
+            const float s = j < nj ? tile[j * ldt + cl] : 0.f;
+            const bool pass = j < nj && s >= thr;                        // nms_utils.py:22 / :74
+            const u64 m = __ballot(pass);
+            if (m == 0) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(cnt, __popcll(m));
+            base = __shfl(base, 0);
+            if (pass) keys[base + __popcll(m & ((1ull << lane) - 1))] = make_key<MODE>(s, (unsigned)(j0 + j));
+        }
+    }
+}
+
+// ---- 2. selection ------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict__ boxes, int n, int C, int max_boxes,
+                                                         float iou_thr, const int* __restrict__ cand_count,
+                                                         u64* __restrict__ cand_keys, int* __restrict__ sel_count,
+                                                         int* __restrict__ sel_idx) {
+    __shared__ u64 skeys[kSortCap];
+    __shared__ f32x4 selbox[kSelCap];
+    __shared__ u64 masks[64];
+    __shared__ u64 wbest[4];
+    __shared__ u64 bcast_key;
+
+    const int bc = blockIdx.x;                 // b * C + c
+    const int b = bc / C;
+    const int k = cand_count[bc];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* out_idx = sel_idx + (long long)bc * max_boxes;
+    const f32x4* bx = (const f32x4*)boxes + (long long)b * n;
+    u64* keys = cand_keys + (long long)bc * n;
+    if (k == 0) {
+        if (tid == 0) sel_count[bc] = 0;
+        return;
+    }
+
+    if (k <= kSortCap) {
+        int np2 = 64;
+        while (np2 < k) np2 <<= 1;
+        for (int i = tid; i < np2; i += 256) skeys[i] = i < k ? keys[i] : kDead;
+        __syncthreads();
+        for (int size = 2; size <= np2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (np2 >> 1); t += 256) {
+                    const int lo = 2 * t - (t & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const u64 x = skeys[lo], y = skeys[hi];
+                    if ((x > y) == up) { skeys[lo] = y; skeys[hi] = x; }
+                }
+                __syncthreads();
+            }
+        if (wave != 0) return;
+        // wave 0: chunked greedy walk over the sorted candidates
+        int nsel = 0;
+        for (int c0 = 0; c0 < k && nsel < max_boxes; c0 += 64) {
+            const int i = c0 + lane;
+            const bool valid = i < k;
+            const unsigned idx = valid ? key_index<MODE>(skeys[i]) : 0u;
+            f32x4 box = {0.f, 0.f, 0.f, 0.f};
+            if (valid) box = bx[idx];
+            bool alive = valid;
+            for (int s = 0; s < nsel; ++s)
+                if (alive && suppresses<MODE>(selbox[s], box, iou_thr)) alive = false;
+            u64 mask = 0;                       // bit j: chunk member j (better ranked) suppresses me
+            for (int j = 0; j < 63; ++j) {
+                f32x4 o;
+                o[0] = __shfl(box[0], j); o[1] = __shfl(box[1], j); o[2] = __shfl(box[2], j); o[3] = __shfl(box[3], j);
+                if (j < lane && suppresses<MODE>(o, box, iou_thr)) mask |= 1ull << j;
+            }
+            masks[lane] = mask;
+            const u64 alive_mask = __ballot(alive);
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): masks[] written by this wave only
+            __builtin_amdgcn_wave_barrier();
+            u64 selected = 0;
+            int cnt = nsel;
+            for (int t = 0; t < 64; ++t) {      // suppression scan (wave-uniform)
+                if (((alive_mask >> t) & 1) && cnt < max_boxes && (masks[t] & selected) == 0) {
+                    selected |= 1ull << t;
+                    ++cnt;
+                }
+            }
+            if ((selected >> lane) & 1) {
+                const int pos = nsel + __popcll(selected & ((1ull << lane) - 1));
+                selbox[pos] = box;
+                out_idx[pos] = (int)idx;
+            }
+            nsel = cnt;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) sel_count[bc] = nsel;
+        return;
+    }
+
+    // k > kSortCap: best-alive passes (no sort)
+    int nsel = 0;
+    bool have = false;
+    u64 selkey = 0;
+    f32x4 sbox = {0.f, 0.f, 0.f, 0.f};
+    while (true) {
+        u64 best = kDead;
+        for (int i = tid; i < k; i += 256) {
+            const u64 key = keys[i];
+            if (key == kDead) continue;
+            if (have) {
+                if (key == selkey) { keys[i] = kDead; continue; }
+                const f32x4 box = bx[key_index<MODE>(key)];
+                if (suppresses<MODE>(sbox, box, iou_thr)) { keys[i] = kDead; continue; }
+            }
+            best = key < best ? key : best;
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            const u64 o = __shfl_xor(best, d);
+            best = o < best ? o : best;
+        }
+        if (lane == 0) wbest[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            u64 m = wbest[0];
+            for (int w = 1; w < 4; ++w) m = wbest[w] < m ? wbest[w] : m;
+            bcast_key = m;
+        }
+        __syncthreads();
+        selkey = bcast_key;
+        if (selkey == kDead) break;
+        const unsigned idx = key_index<MODE>(selkey);
+        sbox = bx[idx];
+        have = true;
+        if (tid == 0) out_idx[nsel] = (int)idx;
+        ++nsel;
+        if (nsel >= max_boxes) break;
+    }
+    if (tid == 0) sel_count[bc] = nsel;
+}
+
+// ---- 3. class-ordered dense output ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                         int n, int C, int max_boxes, const int* __restrict__ sel_count,
+                                                         const int* __restrict__ sel_idx, float* __restrict__ out_boxes,
+                                                         float* __restrict__ out_scores, int* __restrict__ out_labels,
+                                                         int* __restrict__ out_index, int* __restrict__ out_counts) {
+    extern __shared__ int prefix[];            // [C + 1]
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < C; ++c) { prefix[c] = acc; acc += sel_count[(long long)b * C + c]; }
+        prefix[C] = acc;
+        out_counts[b] = acc;
+    }
+    __syncthreads();
+    const long long row0 = (long long)b * C * max_boxes;
+    for (int e = threadIdx.x; e < C * max_boxes; e += 256) {
+        const int c = e / max_boxes, r = e - c * max_boxes;
+        if (r >= prefix[c + 1] - prefix[c]) continue;
+        const int idx = sel_idx[((long long)b * C + c) * max_boxes + r];
+        const long long o = row0 + prefix[c] + r;
+        ((f32x4*)out_boxes)[o] = ((const f32x4*)boxes)[(long long)b * n + idx];      // nms_utils.py:32
+        out_scores[o] = scores[((long long)b * n + idx) * C + c];                    // nms_utils.py:33
+        out_labels[o] = c;                                                           // nms_utils.py:31
+        if (out_index) out_index[o] = idx;
+    }
+}
+
+struct NmsWs { int* cand_count; int* sel_count; int* sel_idx; u64* cand_keys; size_t total; };
+
+static NmsWs nms_layout(void* base, int B, int n, int C, int max_boxes) {
+    NmsWs w;
+    char* p = (char*)base;
+    size_t off = 0;
+    const size_t bc = (size_t)B * C;
+    w.cand_count = (int*)(p + off); off = align_up(off + bc * 4, 256);
+    w.sel_count = (int*)(p + off); off = align_up(off + bc * 4, 256);
+    w.sel_idx = (int*)(p + off); off = align_up(off + bc * (size_t)max_boxes * 4, 256);
+    w.cand_keys = (u64*)(p + off); off = align_up(off + bc * (size_t)n * 8, 256);
+    w.total = off;
+    return w;
+}
+
+template <int MODE>
+static int nms_run(const float* boxes, const float* scores, int B, int n, int C, int max_boxes, float st, float it,
+                   float* ob, float* os, int* ol, int* oi, int* oc, const NmsWs& w, hipStream_t stream) {
+    YOLO_HIP_CHECK(hipMemsetAsync(w.cand_count, 0, (size_t)B * C * 4, stream));
+    const unsigned tiles = (unsigned)((n + kTileJ - 1) / kTileJ);
+    const unsigned ctiles = (unsigned)((C + kTileC - 1) / kTileC);
+    hipLaunchKernelGGL(nms_compact_kernel<MODE>, dim3(tiles, B, ctiles), dim3(256), 0, stream, scores, n, C, st, w.cand_count, w.cand_keys);
+    YOLO_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(nms_select_kernel<MODE>, dim3((unsigned)(B * C)), dim3(256), 0, stream, boxes, n, C, max_boxes, it,
+                       w.cand_count, w.cand_keys, w.sel_count, w.sel_idx);
+    YOLO_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, stream, boxes, scores, n, C, max_boxes,
+                       w.sel_count, w.sel_idx, ob, os, ol, oi, oc);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+}  // namespace yolo
+
+extern "C" size_t yolo_nms_workspace_bytes(int B, int n, int class_num, int max_boxes) {
+    if (B <= 0 || n <= 0 || class_num <= 0 || max_boxes <= 0) return 0;
+    return yolo::nms_layout(nullptr, B, n, class_num, max_boxes).total;
+}
+
+extern "C" int yolo_nms(const float* boxes, const float* scores, int B, int n, int class_num, int max_boxes,
+                        float score_thresh, float iou_thresh, int mode, float* out_boxes, float* out_scores,
+                        int32_t* out_labels, int32_t* out_index, int32_t* out_counts, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    using namespace yolo;
+    YOLO_REQUIRE(boxes && scores && out_boxes && out_scores && out_labels && out_counts && workspace, YOLO_ERR_ARG, "nms: null pointer");
+    YOLO_REQUIRE(B > 0 && n > 0 && class_num > 0 && max_boxes > 0, YOLO_ERR_ARG, "nms: non-positive size");
+    YOLO_REQUIRE(max_boxes <= kSelCap, YOLO_ERR_UNSUPPORTED, "nms: max_boxes %d > %d", max_boxes, kSelCap);
+    YOLO_REQUIRE(class_num <= 4096 && B <= 65535, YOLO_ERR_UNSUPPORTED, "nms: class_num/B out of range");
+    YOLO_REQUIRE((long long)B * class_num < (1ll << 31) && (long long)B * n < (1ll << 31), YOLO_ERR_SHAPE, "nms: problem too large");
+    YOLO_REQUIRE(mode == YOLO_NMS_TF || mode == YOLO_NMS_PY, YOLO_ERR_ARG, "nms: bad mode %d", mode);
+    const NmsWs w = nms_layout(workspace, B, n, class_num, max_boxes);
+    YOLO_REQUIRE(workspace_bytes >= w.total, YOLO_ERR_WORKSPACE, "nms: workspace %zu < %zu bytes", workspace_bytes, w.total);
+    YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "nms: workspace must be 256-byte aligned");
+    if (mode == YOLO_NMS_TF)
+        return nms_run<YOLO_NMS_TF>(boxes, scores, B, n, class_num, max_boxes, score_thresh, iou_thresh, out_boxes, out_scores,
+                                    out_labels, out_index, out_counts, w, (hipStream_t)stream);
+    return nms_run<YOLO_NMS_PY>(boxes, scores, B, n, class_num, max_boxes, score_thresh, iou_thresh, out_boxes, out_scores,
+                                out_labels, out_index, out_counts, w, (hipStream_t)stream);
+}

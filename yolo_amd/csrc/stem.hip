@@ -1,0 +1,150 @@
+// Stem conv (reference yolo_v3/utils/layer_utils.py:31: conv2d(inputs, 32, 3, strides=1) on the RGB
+// image) and small layout helpers.  Cin = 3 makes K = 27: far below an MFMA K-step and not 16-byte
+// addressable, so this layer is a direct f32 VALU convolution.  It is HBM-bound anyway: per pixel
+// it reads 12 B and writes 64 B (bf16) / 128 B (f32) against 1728 FLOP.
+// One thread = one output pixel x COUT output channels; the 27 x COUT folded weights are read with
+// wave-uniform addresses (scalar loads -> SGPR operands of v_fmac).
+#include "common.h"
+
+namespace yolo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <bool BF16, int COUT>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, char* __restrict__ out,
+                                                   int B, int H, int W, int out_ld, int out_coff, int leaky) {
+    const long long npix = (long long)B * H * W;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= npix) return;
+    const int x = (int)(m % W);
+    const long long t = m / W;
+    const int y = (int)(t % H);
+    const long long b = t / H;
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = bias[n];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = x + kx - 1;
+            const bool ok = yok && ix >= 0 && ix < W;
+            const float* px = in + ((b * H + iy) * W + ix) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = ok ? px[c] : 0.f;
+                const float* wr = w + ((ky * 3 + kx) * 3 + c) * COUT;
+#pragma unroll
+                for (int n = 0; n < COUT; ++n) acc[n] = __builtin_fmaf(v, wr[n], acc[n]);
+            }
+        }
+    }
+    if (leaky) {
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = 0.55f * acc[n] + 0.45f * __builtin_fabsf(acc[n]);
+    }
+    if constexpr (BF16) {
+        char* op = out + (m * out_ld + out_coff) * 2;
+#pragma unroll
+        for (int n = 0; n < COUT; n += 8) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[n + e];
+            *(bf16x8*)(op + n * 2) = o;
+        }
+    } else {
+        char* op = out + (m * out_ld + out_coff) * 4;
+#pragma unroll
+        for (int n = 0; n < COUT; n += 4) {
+            f32x4 o = {acc[n], acc[n + 1], acc[n + 2], acc[n + 3]};
+            *(f32x4*)(op + n * 4) = o;
+        }
+    }
+}
+
+int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream) {
+    YOLO_REQUIRE(p.Cin == 3 && p.ksize == 3 && p.stride == 1 && p.Cout == 32 && p.in_ld == 3 && p.in_coff == 0,
+                 YOLO_ERR_UNSUPPORTED, "stem: only 3x3 s1 3->32 on a dense RGB image is implemented");
+    YOLO_REQUIRE(p.out_ld % 8 == 0 && p.out_coff % 8 == 0, YOLO_ERR_SHAPE, "stem: output stride");
+    const long long npix = (long long)p.B * p.H * p.W;
+    const unsigned grid = (unsigned)((npix + 255) / 256);
+    if (dtype == YOLO_DTYPE_BF16)
+        hipLaunchKernelGGL((stem_kernel<true, 32>), dim3(grid), dim3(256), 0, stream, (const float*)p.in,
+                           (const float*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
+    else
+        hipLaunchKernelGGL((stem_kernel<false, 32>), dim3(grid), dim3(256), 0, stream, (const float*)p.in,
+                           (const float*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+// ---- f32 <-> bf16 casts used by the single-layer entry point (yolo_conv_forward) ---------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        if (i + 4 <= n) {
+            f32x4 v = *(const f32x4*)(in + i);
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *(bf16x4*)(out + i) = o;
+        } else {
+            for (size_t j = i; j < n; ++j) out[j] = (__bf16)in[j];
+        }
+    }
+}
+
+__global__ void cast_bf16_f32_kernel(const __bf16* __restrict__ in, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = (float)in[i];
+}
+
+static unsigned cast_grid(size_t n, int per_thread) {
+    size_t g = (n + 256ull * per_thread - 1) / (256ull * per_thread);
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int launch_cast_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cast_grid(n, 4)), dim3(256), 0, stream, in, (__bf16*)out, n);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+int launch_cast_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(cast_grid(n, 1)), dim3(256), 0, stream, (const __bf16*)in, out, n);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+// ---- upsample_layer (layer_utils.py:67-72), exact-2x case: src = dst // 2 ----------------------
+__global__ void upsample2x_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int B, int H, int W, int C4) {
+    const size_t total = (size_t)B * 2 * H * 2 * W * C4;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int x = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int y = (int)(t % (2 * H));
+        const size_t b = t / (2 * H);
+        out[i] = in[((b * H + (y >> 1)) * W + (x >> 1)) * C4 + c];
+    }
+}
+
+}  // namespace yolo
+
+extern "C" int yolo_upsample2x(const float* in, int B, int H, int W, int C, float* out, void* stream) {
+    YOLO_REQUIRE(in && out, YOLO_ERR_ARG, "upsample2x: null pointer");
+    YOLO_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, YOLO_ERR_SHAPE, "upsample2x: bad shape (C %% 4 == 0 required)");
+    const size_t total = (size_t)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(yolo::upsample2x_kernel, dim3(yolo::cast_grid(total, 1)), dim3(256), 0, (hipStream_t)stream,
+                       (const yolo::f32x4*)in, (yolo::f32x4*)out, B, H, W, C / 4);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}

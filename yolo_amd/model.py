@@ -1,0 +1,122 @@
+# coding=utf-8
+"""`yolov3` with the interface of reference yolo_v3/model.py:14-153, executed by libyolo_hip.so.
+
+Differences forced by eager execution (there is no TF graph / Saver): weights come from
+`load_darknet_weights(path)` / `load_weight_stream(array)` (the Darknet file layout that the
+reference's convert_weight.py + misc_utils.load_weights consume), tensors are torch-ROCm tensors.
+"""
+from __future__ import division, print_function
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, _tensor
+from .utils import misc_utils
+
+
+class yolov3(object):
+
+    def __init__(self, class_num, anchors, batch_norm_decay=0.9, dtype="fp32"):
+        # model.py:16-19 (batch_norm_decay only matters for training; kept for signature parity)
+        self.class_num = class_num
+        self.anchors = np.asarray(anchors, np.float32).reshape(-1, 2)
+        self.batch_norm_decay = batch_norm_decay
+        self.dtype = dtype
+        self._dtype_code = _lib.DTYPES[dtype]
+        self._net = None
+        self._ws = None
+        self.img_size = None
+
+    # ---- weights (replaces tf.train.Saver.restore at test_single_image.py:35-36) -----------------
+    def load_weight_stream(self, stream):
+        """stream: float32 body of a Darknet .weights file (conv order = call order of forward)."""
+        stream = np.ascontiguousarray(stream, dtype=np.float32)
+        _tensor.device()
+        self._free()
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().yolo_net_create(self.class_num, self._dtype_code, stream.ctypes.data,
+                                              stream.size, ctypes.byref(h)))
+        self._net = h
+        return self
+
+    def load_darknet_weights(self, weights_file):
+        return self.load_weight_stream(misc_utils.read_darknet_weights(weights_file))
+
+    def _free(self):
+        if getattr(self, "_net", None) is not None:
+            _lib.lib().yolo_net_destroy(self._net)
+            self._net = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    # ---- model.py:21-67 ------------------------------------------------------------------------------
+    def forward(self, inputs, is_training=False, reuse=False):
+        if is_training:
+            raise ValueError("yolo_amd implements the inference path only (is_training=False)")
+        if self._net is None:
+            raise RuntimeError("weights not loaded: call load_darknet_weights()/load_weight_stream() first")
+        x = _tensor.as_dev_f32(inputs)
+        if x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError("inputs must be [N, H, W, 3], got %s" % (tuple(x.shape),))
+        B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        self.img_size = (H, W)                                   # model.py:22
+        L = _lib.lib()
+        need = L.yolo_net_workspace_bytes(self._net, B, H, W)
+        if need == 0:
+            raise ValueError("unsupported input shape %s (H, W must be multiples of 32)" % (tuple(x.shape),))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = _tensor.workspace(need)
+        nout = 3 * (5 + self.class_num)
+        fms = [_tensor.empty((B, H // r, W // r, nout)) for r in (32, 16, 8)]
+        _lib.check(L.yolo_net_forward(self._net, x.data_ptr(), B, H, W, self._ws.data_ptr(), self._ws.numel(),
+                                      fms[0].data_ptr(), fms[1].data_ptr(), fms[2].data_ptr(), _tensor.stream_ptr()))
+        return fms[0], fms[1], fms[2]
+
+    # ---- model.py:69-108 -----------------------------------------------------------------------------
+    def reorg_layer(self, feature_map, anchors):
+        if self.img_size is None:
+            raise RuntimeError("reorg_layer needs img_size recorded by forward() (model.py:22,78)")
+        fm = _tensor.as_dev_f32(feature_map)
+        B, gh, gw = int(fm.shape[0]), int(fm.shape[1]), int(fm.shape[2])
+        anc = np.ascontiguousarray(anchors, np.float32).reshape(3, 2)
+        boxes = _tensor.empty((B, gh, gw, 3, 4))
+        _lib.check(_lib.lib().yolo_reorg_boxes(fm.data_ptr(), B, gh, gw, self.img_size[0], self.img_size[1],
+                                               self.class_num, anc.ctypes.data, boxes.data_ptr(),
+                                               _tensor.stream_ptr()))
+        v = fm.view(B, gh, gw, 3, 5 + self.class_num)                         # model.py:81
+        conf_logits, prob_logits = v[..., 4:5], v[..., 5:]                    # model.py:87
+        gx = torch.arange(gw, dtype=torch.float32, device=fm.device)
+        gy = torch.arange(gh, dtype=torch.float32, device=fm.device)
+        x_y_offset = torch.stack(torch.meshgrid(gx, gy, indexing="xy"), dim=-1).reshape(gh, gw, 1, 2)   # :90-97
+        return x_y_offset, boxes, conf_logits, prob_logits
+
+    # ---- model.py:110-153 ----------------------------------------------------------------------------
+    def predict(self, feature_maps, return_scores=False):
+        """-> (boxes [N,n,4] x0y0x1y1, confs [N,n,1], probs [N,n,C]); with return_scores also
+        scores = confs * probs (the product the caller forms at test_single_image.py:38), fused."""
+        fm1, fm2, fm3 = [_tensor.as_dev_f32(f) for f in feature_maps]
+        B = int(fm1.shape[0])
+        if self.img_size is None:
+            self.img_size = (int(fm1.shape[1]) * 32, int(fm1.shape[2]) * 32)
+        H, W = self.img_size
+        C = self.class_num
+        n = 3 * sum((H // r) * (W // r) for r in (32, 16, 8))
+        boxes = _tensor.empty((B, n, 4))
+        confs = _tensor.empty((B, n, 1))
+        probs = _tensor.empty((B, n, C))
+        scores = _tensor.empty((B, n, C)) if return_scores else None
+        anc = np.ascontiguousarray(self.anchors, np.float32)
+        if anc.shape != (9, 2):
+            raise ValueError("predict needs 9 anchors, got %s" % (anc.shape,))
+        _lib.check(_lib.lib().yolo_decode(fm1.data_ptr(), fm2.data_ptr(), fm3.data_ptr(), B, H, W, C,
+                                          anc.ctypes.data, boxes.data_ptr(), confs.data_ptr(), probs.data_ptr(),
+                                          _tensor.ptr(scores), _tensor.stream_ptr()))
+        if return_scores:
+            return boxes, confs, probs, scores
+        return boxes, confs, probs
