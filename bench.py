@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py - YOLOv3-416 COCO-80 end-to-end (conv + decode + NMS) images/sec on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run)
+
+A step = one pass of the hot path over one batch of 64 synthetic 416x416 images per GPU that are
+already resident in HBM: yolov3.forward (bf16 MFMA conv stack) -> predict (+ fused conf*prob) ->
+per-class NMS (gpu_nms defaults 50 / 0.5 / 0.5).  Images are independent, so ranks share nothing
+(weak scaling, no collective in the timed region).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+F32_PEAK_TFLOPS = 157.3
+
+
+def conv_flops_per_image(info, H, W):
+    """2*MAC per conv: output resolution follows the strides along the plan."""
+    # resolution of every conv's OUTPUT: replay the architecture (stride-2 convs halve; the two
+    # upsample branches return to the route resolution; heads keep theirs).
+    flops = []
+    h, w = H, W
+    res_at = {}
+    for i, (cin, cout, k, s) in enumerate(info):
+        if i == 59:            # inter1 conv consumes conv 56's output (13x13)
+            h, w = H // 32, W // 32
+        elif i == 60:          # yolo_block on concat1 (26x26)
+            h, w = H // 16, W // 16
+        elif i == 67:
+            h, w = H // 16, W // 16
+        elif i == 68:
+            h, w = H // 8, W // 8
+        h, w = h // s, w // s
+        flops.append(2.0 * h * w * cout * cin * k * k)
+    return flops
+
+
+def cpu_baseline(n_images, threads):
+    """The oracle (CPU restatement of the reference: TF is not installable offline) on host cores."""
+    from oracle import yolo_oracle as O
+    torch.set_num_threads(threads)
+    specs = O.yolov3_conv_specs(80)
+    params = O.split_darknet_stream(specs, O.synth_darknet_stream(specs, seed=1234))
+    rng = np.random.default_rng(0)
+    img = rng.random((1, 416, 416, 3), dtype=np.float32)
+    O.detect(params, O.YOLO_ANCHORS, img, max_boxes=50, score_thresh=0.5, iou_thresh=0.5)     # warm
+    t0 = time.perf_counter()
+    for i in range(n_images):
+        img = rng.random((1, 416, 416, 3), dtype=np.float32)
+        O.detect(params, O.YOLO_ANCHORS, img, max_boxes=50, score_thresh=0.5, iou_thresh=0.5)
+    dt = time.perf_counter() - t0
+    return {"value": n_images / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d images, batch 1, 416x416, oracle forward+predict+gpu_nms(50,0.5,0.5), torch-CPU fp32 convs "
+                      "(CPU restatement of the reference; TensorFlow not installable offline)" % n_images}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=6)
+    ap.add_argument("--layer-table", default="", help="write the per-layer timing table to this file")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    from yolo_amd.model import yolov3
+    from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
+    from yolo_amd.utils.nms_utils import gpu_nms_batched
+    from oracle import yolo_oracle as O          # only for the synthetic weight recipe + cpu_baseline leg
+
+    B, S = args.batch, args.size
+    specs = O.yolov3_conv_specs(80)
+    stream = O.synth_darknet_stream(specs, seed=1234)
+    net = yolov3(80, DEFAULT_ANCHORS, dtype=args.dtype).load_weight_stream(stream)
+    rng = np.random.default_rng(1 + rank)
+    images = torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).cuda()
+
+    def step():
+        fms = net.forward(images)
+        boxes, _, _, scores = net.predict(fms, return_scores=True)
+        return gpu_nms_batched(boxes, scores, 80, 50, 0.5, 0.5)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ndet = int(out[4].sum().item())
+
+    # ---- roofline of the dominant kernel (conv_igemm 128x128 tile), HIP events on the launch stream ----
+    reps = 5
+    acc = None
+    for _ in range(reps):
+        _, ms, info = net.forward_timed(images)
+        acc = ms.astype(np.float64) if acc is None else acc + ms
+    layer_ms = acc / reps
+    flops = conv_flops_per_image(info, S, S)
+    dom = [i for i, (cin, cout, k, s) in enumerate(info) if cin != 3 and cout > 64]     # 128x128-tile launches
+    dom_flops = sum(flops[i] for i in dom) * B
+    dom_ms = float(sum(layer_ms[i] for i in dom))
+    peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
+    achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s,128,128,2,2>" % ("bf16" if args.dtype == "bf16" else "f32"),
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "launches_per_step": len(dom),
+                "avg_launch_ms": round(dom_ms / len(dom), 5),
+                "flops_per_launch_avg": dom_flops / len(dom),
+                "conv_stack_ms": round(float(layer_ms.sum()), 4),
+                "conv_stack_tflops": round(sum(flops) * B / (float(layer_ms.sum()) * 1e-3) / 1e12, 2)}
+    if args.layer_table and rank == 0:
+        with open(args.layer_table, "w") as f:
+            f.write("# layer cin cout k stride ms GFLOP TFLOP/s   (batch %d, %dx%d, %s)\n" % (B, S, S, args.dtype))
+            for i, ((cin, cout, k, s), ms_i) in enumerate(zip(info, layer_ms)):
+                f.write("%2d %4d %4d %d %d %8.4f %9.3f %8.2f\n" % (i, cin, cout, k, s, ms_i, flops[i] * B / 1e9,
+                                                                   flops[i] * B / (ms_i * 1e-3) / 1e12))
+
+    if rank == 0:
+        res = {
+            "metric": "YOLOv3-416 images/sec end-to-end (conv+decode+NMS)",
+            "value": round(world * B * args.steps / dt, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "YOLOv3-%d COCO-80, batch %d per GPU, %s conv stack + fp32 decode + per-class NMS "
+                                   "(max_boxes 50, score 0.5, iou 0.5), synthetic images and seeded random-init Darknet-order weights"
+                                   % (S, B, args.dtype),
+                       "global_batch": world * B, "detections_last_step": ndet, "parallelism": "image-sharded dp%d" % world},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_images, min(16, os.cpu_count() or 1))
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,8 +55,15 @@ size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int W);
 /* images [B,H,W,3] f32 -> fm1 [B,H/32,W/32,3*(5+C)], fm2 [B,H/16,W/16,.], fm3 [B,H/8,W/8,.] f32. */
 int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
                      size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream);
-/* Number of conv layers of the plan (75 for YOLOv3). */
+/* Number of conv layers of the plan (75 for YOLOv3) and the static shape of layer i. */
 int yolo_net_num_layers(const YoloNet* net);
+int yolo_net_layer_info(const YoloNet* net, int layer, int* cin, int* cout, int* ksize, int* stride);
+/* Measurement aid (no counterpart in the reference): yolo_net_forward with a hipEvent recorded on
+ * `stream` before every layer; SYNCHRONISES the stream, then writes per-layer device milliseconds to
+ * HOST layer_ms[n_layers] (n_layers must equal yolo_net_num_layers). */
+int yolo_net_forward_timed(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
+                           size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream,
+                           float* layer_ms, int n_layers);
 
 /* ---- one conv layer: replaces conv2d (yolo_v3/utils/layer_utils.py:9-21) under the arg_scope of
  * yolo_v3/model.py:32-36 (conv no-bias + BN(eps 1e-5, inference) + leaky 0.1), or, with bn == 0,

@@ -22,6 +22,8 @@ SIGNATURES = {
     "yolo_net_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "yolo_net_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "yolo_net_num_layers": (_i, [_vp]),
+    "yolo_net_layer_info": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "yolo_net_forward_timed": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i]),
     "yolo_conv_create": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_vp)]),
     "yolo_conv_destroy": (_i, [_vp]),
     "yolo_conv_workspace_bytes": (_sz, [_vp, _i, _i, _i]),

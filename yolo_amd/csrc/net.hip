@@ -317,8 +317,8 @@ extern "C" size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int
     return P->ws_bytes;
 }
 
-extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
-                                float* fm1, float* fm2, float* fm3, void* stream) {
+static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                        float* fm1, float* fm2, float* fm3, void* stream, hipEvent_t* events) {
     YOLO_REQUIRE(net && images && workspace && fm1 && fm2 && fm3, YOLO_ERR_ARG, "forward: null pointer");
     const Plan* P = nullptr;
     int rc = get_plan(net, B, H, W, &P);
@@ -349,9 +349,45 @@ extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H,
             p.res = (char*)workspace + t.offset; p.res_ld = t.ld; p.res_coff = 0;
         }
         p.upsample = st.upsample;
+        if (events) YOLO_HIP_CHECK(hipEventRecord(events[st.layer], (hipStream_t)stream));
         rc = run_conv(L, p, (hipStream_t)stream);
         if (rc != YOLO_OK) return rc;
     }
+    if (events) YOLO_HIP_CHECK(hipEventRecord(events[P->steps.size()], (hipStream_t)stream));
+    return YOLO_OK;
+}
+
+extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                                float* fm1, float* fm2, float* fm3, void* stream) {
+    return forward_impl(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream, nullptr);
+}
+
+// Measurement aid: one forward with a hipEvent before every layer's launch (on `stream`), then a stream
+// synchronisation; layer_ms[i] = device time between the launch of layer i and of layer i+1.
+extern "C" int yolo_net_forward_timed(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
+                                      size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream,
+                                      float* layer_ms, int n_layers) {
+    YOLO_REQUIRE(net && layer_ms, YOLO_ERR_ARG, "forward_timed: null pointer");
+    const int nl = (int)net->layers.size();
+    YOLO_REQUIRE(n_layers == nl, YOLO_ERR_ARG, "forward_timed: layer_ms must hold %d floats", nl);
+    std::vector<hipEvent_t> ev(nl + 1);
+    for (auto& e : ev) YOLO_HIP_CHECK(hipEventCreate(&e));
+    int rc = forward_impl(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream, ev.data());
+    if (rc == YOLO_OK) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) { set_error("forward_timed: sync failed: %s", hipGetErrorString(e)); rc = YOLO_ERR_HIP; }
+    }
+    for (int i = 0; i < nl && rc == YOLO_OK; ++i)
+        if (hipEventElapsedTime(&layer_ms[i], ev[i], ev[i + 1]) != hipSuccess) { set_error("forward_timed: elapsed"); rc = YOLO_ERR_HIP; }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// Static description of layer i (tests, benchmarks): fills cin, cout, ksize, stride.
+extern "C" int yolo_net_layer_info(const YoloNet* net, int layer, int* cin, int* cout, int* ksize, int* stride) {
+    YOLO_REQUIRE(net && layer >= 0 && layer < (int)net->specs.size() && cin && cout && ksize && stride, YOLO_ERR_ARG, "layer_info: bad argument");
+    const Spec& s = net->specs[layer];
+    *cin = s.cin; *cout = s.cout; *ksize = s.k; *stride = s.stride;
     return YOLO_OK;
 }
 

@@ -78,6 +78,38 @@ class yolov3(object):
                                       fms[0].data_ptr(), fms[1].data_ptr(), fms[2].data_ptr(), _tensor.stream_ptr()))
         return fms[0], fms[1], fms[2]
 
+    def forward_timed(self, inputs):
+        """Measurement aid: forward with per-layer hipEvent timing -> (fms, ms[75], [(cin,cout,k,stride)])."""
+        x = _tensor.as_dev_f32(inputs)
+        B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        self.img_size = (H, W)
+        L = _lib.lib()
+        need = L.yolo_net_workspace_bytes(self._net, B, H, W)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = _tensor.workspace(need)
+        nout = 3 * (5 + self.class_num)
+        fms = [_tensor.empty((B, H // r, W // r, nout)) for r in (32, 16, 8)]
+        nl = L.yolo_net_num_layers(self._net)
+        ms = np.zeros(nl, np.float32)
+        _lib.check(L.yolo_net_forward_timed(self._net, x.data_ptr(), B, H, W, self._ws.data_ptr(), self._ws.numel(),
+                                            fms[0].data_ptr(), fms[1].data_ptr(), fms[2].data_ptr(),
+                                            _tensor.stream_ptr(), ms.ctypes.data, nl))
+        info = []
+        for i in range(nl):
+            v = [ctypes.c_int() for _ in range(4)]
+            _lib.check(L.yolo_net_layer_info(self._net, i, *[ctypes.byref(t) for t in v]))
+            info.append(tuple(t.value for t in v))
+        return fms, ms, info
+
+    def detect(self, inputs, max_boxes=30, score_thresh=0.4, iou_thresh=0.5):
+        """The hot chain of test_single_image.py:31-40 for a batch, per image: forward -> predict ->
+        conf*prob -> per-class NMS.  Defaults are that script's thresholds (:39).
+        -> (boxes [N,C*max_boxes,4], scores, labels int32, keep-index int32, counts int32 [N])."""
+        from .utils.nms_utils import gpu_nms_batched
+        fms = self.forward(inputs)
+        boxes, _, _, scores = self.predict(fms, return_scores=True)
+        return gpu_nms_batched(boxes, scores, self.class_num, max_boxes, score_thresh, iou_thresh)
+
     # ---- model.py:69-108 -----------------------------------------------------------------------------
     def reorg_layer(self, feature_map, anchors):
         if self.img_size is None:
