@@ -93,11 +93,10 @@ def main():
     from yolo_amd.model import yolov3
     from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
     from yolo_amd.utils.nms_utils import gpu_nms_batched
-    from oracle import yolo_oracle as O          # only for the synthetic weight recipe + cpu_baseline leg
+    from yolo_amd.weights import synth_darknet_stream
 
     B, S = args.batch, args.size
-    specs = O.yolov3_conv_specs(80)
-    stream = O.synth_darknet_stream(specs, seed=1234)
+    stream = synth_darknet_stream(80, seed=1234)
     net = yolov3(80, DEFAULT_ANCHORS, dtype=args.dtype).load_weight_stream(stream)
     rng = np.random.default_rng(1 + rank)
     images = torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).cuda()

@@ -367,3 +367,55 @@ def test_nms_stress_608_properties(torch_cuda, oracle):
         kb, ks = ob[ol == c], osc[ol == c]
         again = oracle.tf_non_max_suppression(kb, ks, 50, 0.5)
         np.testing.assert_array_equal(again, np.arange(len(kb)))
+
+
+# ---------------------------------------------------------------------------------------------
+# layer-level drop-in functions (yolo_v3/utils/layer_utils.py signatures)
+# ---------------------------------------------------------------------------------------------
+def test_layer_utils_compose_like_forward(net_f32, torch_cuda, oracle, weight_stream):
+    """darknet53_body + yolo_block + conv2d + upsample_layer assembled exactly like model.py:37-65
+    reproduce the fused whole-net plan (and therefore the reference golden)."""
+    from yolo_amd import weights
+    from yolo_amd.utils import layer_utils as lu
+    g = load_golden("g1_convstack_64.npz")
+    params = weights.split_stream(weight_stream, 80)
+    torch = torch_cuda
+    with lu.variable_scope(params, "fp32") as scope:
+        route_1, route_2, route_3 = lu.darknet53_body(g["img"])
+        inter1, net = lu.yolo_block(route_3, 512)
+        fm1 = lu.conv2d(net, 255, 1)
+        inter1 = lu.conv2d(inter1, 256, 1)
+        inter1 = lu.upsample_layer(inter1, list(route_2.shape))
+        concat1 = torch.cat([inter1, route_2], dim=3)
+        inter2, net = lu.yolo_block(concat1, 256)
+        fm2 = lu.conv2d(net, 255, 1)
+        inter2 = lu.conv2d(inter2, 128, 1)
+        inter2 = lu.upsample_layer(inter2, list(route_1.shape))
+        concat2 = torch.cat([inter2, route_1], dim=3)
+        _, net = lu.yolo_block(concat2, 128)
+        fm3 = lu.conv2d(net, 255, 1)
+        assert scope.next == 75
+    for got, key in zip((fm1, fm2, fm3), ("fm1", "fm2", "fm3")):
+        ok, maxerr, rms = rel_rms_ok(got.cpu().numpy(), g[key], 1e-3)
+        assert ok, (key, maxerr, rms)
+    x = np.random.default_rng(2).normal(size=(2, 5, 7, 8)).astype(np.float32)
+    up = lu.upsample_layer(x, [2, 10, 14, 8])
+    np.testing.assert_array_equal(up.cpu().numpy(), oracle.upsample_layer(x, (2, 10, 14, 8)))
+    with pytest.raises(ValueError):
+        lu.upsample_layer(x, [2, 15, 21, 8])
+
+
+def test_detect_end_to_end_vs_oracle(net_f32, oracle, oracle_params):
+    """Counterpart of test_single_image.py:31-40 (30 / 0.4 / 0.5): fp32 HIP chain vs oracle chain.
+    Scores differ in the last bits, so compare as sets with tolerance; exact NMS parity is tested above."""
+    img = np.random.default_rng(4).random((1, 416, 416, 3), dtype=np.float32)
+    ob, osc, ol, oi, oc = net_f32.detect(img)
+    m = int(oc[0])
+    rb, rs, rl = oracle.detect(oracle_params, oracle.YOLO_ANCHORS, img)
+    assert abs(m - len(rl)) <= max(2, len(rl) // 50)
+    got = {(int(l), int(i)) for l, i in zip(ol[0, :m].cpu().numpy(), oi[0, :m].cpu().numpy())}
+    fms = oracle.forward(oracle_params, img)
+    b, c, p = oracle.predict(fms, oracle.YOLO_ANCHORS, (416, 416))
+    _, _, rl2, ri2 = oracle.gpu_nms(b, c * p, 80, 30, 0.4, 0.5, return_indices=True)
+    ref = {(int(l), int(i)) for l, i in zip(rl2, ri2)}
+    assert len(got & ref) >= 0.97 * len(ref), (len(got), len(ref), len(got & ref))

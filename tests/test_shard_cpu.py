@@ -1,0 +1,95 @@
+"""CPU: the multi-GPU (image-sharded) path - shard arithmetic and the optional final all-gather of
+detections, exercised with world_size 2 over gloo (RCCL is the same call with backend nccl)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_shard_bounds_partition():
+    from yolo_amd.shard import shard_bounds
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 4, 8):
+            bounds = [shard_bounds(n, r, world) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            for (a, b), (c, d) in zip(bounds, bounds[1:]):
+                assert b == c
+            sizes = [b - a for a, b in bounds]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_bounds(512, 3, 8) == (192, 256)
+    with pytest.raises(ValueError):
+        shard_bounds(8, 2, 2)
+
+
+def _worker(rank, world, port, n_images, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from yolo_amd.shard import all_gather_detections, pack_detections, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        R = 12
+        g = torch.Generator().manual_seed(1234)
+        boxes = torch.rand((n_images, R, 4), generator=g)
+        scores = torch.rand((n_images, R), generator=g)
+        labels = torch.randint(0, 80, (n_images, R), generator=g, dtype=torch.int32)
+        counts = torch.randint(0, R + 1, (n_images,), generator=g, dtype=torch.int32)
+        lo, hi = shard_bounds(n_images, rank, world)
+        wire = pack_detections(boxes[lo:hi], scores[lo:hi], labels[lo:hi], counts[lo:hi])
+        out_w, out_c = all_gather_detections(wire, counts[lo:hi], n_images)
+        ref = pack_detections(boxes, scores, labels, counts)
+        assert out_w.shape == (n_images, R, 6)
+        assert torch.equal(out_w, ref) and torch.equal(out_c, counts)
+        # rows past counts are zero, label column is exact
+        for i in range(n_images):
+            assert torch.all(out_w[i, int(counts[i]):] == 0)
+            assert torch.equal(out_w[i, :int(counts[i]), 5].to(torch.int32), labels[i, :int(counts[i])])
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [8, 7])
+def test_all_gather_detections_gloo_world2(tmp_path, n_images):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + n_images
+    mp.spawn(_worker, args=(2, port, n_images, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_weight_stream_roundtrip_and_split(tmp_path, oracle, weight_stream):
+    """Product-side stream helpers agree with the oracle's (and with the Darknet file layout)."""
+    from yolo_amd import weights
+    from yolo_amd.utils.misc_utils import read_darknet_weights
+    assert weights.stream_length(weights.yolov3_conv_specs(80)) == 62001757
+    small = weight_stream[:100000]
+    p = str(tmp_path / "w.weights")
+    weights.write_darknet_weights(p, small)
+    assert os.path.getsize(p) == 20 + 4 * len(small)
+    np.testing.assert_array_equal(read_darknet_weights(p), small)
+    np.testing.assert_array_equal(oracle.read_darknet_weights(p), small)
+    mine = weights.split_stream(weight_stream, 80)
+    ref = oracle.split_darknet_stream(oracle.yolov3_conv_specs(80), weight_stream)
+    for i in (0, 1, 25, 58, 59, 74):
+        for k in ref[i]:
+            np.testing.assert_array_equal(mine[i][k], ref[i][k])
+    np.testing.assert_array_equal(weights.synth_darknet_stream(80, seed=1234)[::100003], weight_stream[::100003])
+
+
+def test_misc_utils_parsers(tmp_path):
+    from yolo_amd.utils import misc_utils
+    a = tmp_path / "anchors.txt"
+    a.write_text("10,13, 16,30, 33,23, 30,61, 62,45, 59,119, 116,90,  156,198,  373,326")
+    got = misc_utils.parse_anchors(str(a))
+    assert got.dtype == np.float32 and got.shape == (9, 2)
+    np.testing.assert_array_equal(got, misc_utils.DEFAULT_ANCHORS)
+    n = tmp_path / "names.txt"
+    n.write_text("person\nbicycle\ncar\n")
+    assert misc_utils.read_class_names(str(n)) == {0: "person", 1: "bicycle", 2: "car"}
+    names = misc_utils.coco_class_names()
+    assert len(names) == 80 and names[0] == "person" and names[16] == "dog" and names[79] == "toothbrush"

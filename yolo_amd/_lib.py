@@ -45,6 +45,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s not found: build it with `make -C yolo_amd/csrc` "
                                "(or `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        # torch-ROCm must load ITS HIP runtime first: libyolo_hip.so then binds to the same
+        # libamdhip64 instance, so torch allocations, streams and our launches share one context.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
