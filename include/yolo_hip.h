@@ -81,6 +81,10 @@ size_t yolo_conv_workspace_bytes(const YoloConv* conv, int B, int H, int W);
 int yolo_conv_forward(YoloConv* conv, const float* in, int B, int H, int W, const float* residual,
                       float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement aid (no counterpart in the reference): average device time of `iters` launches of this
+ * layer on internally allocated buffers of the layer's dtype.  Allocates and synchronises. */
+int yolo_conv_benchmark(YoloConv* conv, int B, int H, int W, int with_residual, int iters, float* avg_ms);
+
 /* ---- replaces upsample_layer (layer_utils.py:67-72) for the exact-2x case the network uses. */
 int yolo_upsample2x(const float* in, int B, int H, int W, int C, float* out, void* stream);
 

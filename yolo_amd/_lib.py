@@ -28,6 +28,7 @@ SIGNATURES = {
     "yolo_conv_destroy": (_i, [_vp]),
     "yolo_conv_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "yolo_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "yolo_conv_benchmark": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "yolo_upsample2x": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "yolo_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yolo_reorg_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

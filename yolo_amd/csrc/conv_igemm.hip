@@ -14,6 +14,7 @@
 //   * math: v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32), f32 accumulate.
 //   * double-buffered LDS, one barrier per 128-byte K-step.
 //   * epilogue through LDS so that stores are 16 B per lane, channel-contiguous.
+#include <cstdlib>
 #include "common.h"
 
 namespace yolo {
@@ -24,6 +25,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __attribute__((aligned(256))) static const unsigned char g_zero_page[256] = {0};
+
+#ifdef YOLO_CONV_STAMPS
+// Diagnostic build only (make STAMPS=1): per-phase s_memtime sums of wave 0 of every 64th block.
+// Never compiled into the shipped library; stamp values go to a buffer nothing else reads.
+__device__ unsigned long long g_stamps[64 * 8];
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[i] += t_ - tl_; tl_ = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 struct ConvK {
     const char* in;
@@ -43,162 +53,18 @@ struct ConvK {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),  \
                                      (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+// ---- shared epilogue: bias + activation in registers, transpose through LDS, then per thread one
+// (pixel, 8-channel) chunk at a time: residual add, optional 2x2 upsample scatter, 16 B/lane stores.
+// All residual loads of a thread are issued before the first one is consumed.
+// (A register-direct epilogue with the MFMA operands swapped - 4 consecutive channels per lane, 8-byte
+// stores, no LDS - was measured 15-25 % SLOWER per layer: 32 partial lines per store instruction.)
+template <bool BF16, int BM, int BN, int TM, int TN, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], char* lds, int m0, int n0,
+                                              int wm0, int wn0, int tid, int fr, int fh) {
     constexpr int SZ = BF16 ? 2 : 4;
-    constexpr int TM = BM / WARPS_M / 32;
-    constexpr int TN = BN / WARPS_N / 32;
-    constexpr int A_BYTES = BM * 128;
-    constexpr int B_BYTES = BN * 128;
-    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
-    constexpr int AI = BM / 32;   // LDS-DMA instructions per wave per K-step for A
-    constexpr int BI = BN / 32;
-    constexpr int LDC = BN + 4;   // epilogue tile row stride in floats
-    static_assert(WARPS_M * WARPS_N == 4, "4 waves");
-
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of
-    // tiles so that the N-tiles of one M-tile (same input rows) and neighbouring M-tiles (3x3 halo)
-    // hit the same L2.  Bijective for any grid size.
-    int tile;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int mt = tile / p.ntn;
-    const int nt = tile - mt * p.ntn;
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
-
-    const int CinB = p.Cin * SZ;
-    const int ntaps = p.ksize * p.ksize;
-    const int HoWo = p.Ho * p.Wo;
-
-    // ---- per-thread loader state ---------------------------------------------------------
-    // This lane fills LDS slot (row = 8g + (lane>>3), chunk' = lane&7) of row-group g = wave + 4i;
-    // it therefore fetches logical chunk c = chunk' ^ ((row>>1)&7), identical for all its rows.
-    const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-    long long a_off[AI];
-    unsigned a_mask[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int row = 8 * (wave + 4 * i) + (lane >> 3);
-        const int m = m0 + row;
-        unsigned mask = 0;
-        long long off = 0;
-        if (m < p.M) {
-            const int b = m / HoWo;
-            const int r = m - b * HoWo;
-            const int oy = r / p.Wo;
-            const int ox = r - oy * p.Wo;
-            const int iy0 = oy * p.stride - p.pad;
-            const int ix0 = ox * p.stride - p.pad;
-            off = (((long long)b * p.H + iy0) * p.W + ix0) * (long long)p.in_ld * SZ;
-            for (int t = 0; t < ntaps; ++t) {
-                const int ky = (t * 11) >> 5, kx = t - ky * 3;   // ksize is 1 or 3
-                const int iy = iy0 + ky, ix = ix0 + kx;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
-            }
-        }
-        a_off[i] = off;
-        a_mask[i] = mask;
-    }
-    int tap = 0;
-    int cib = chunk * 16;
-    while (cib >= CinB) { cib -= CinB; ++tap; }
-    const char* wsrc = p.w + (long long)(n0 + 8 * wave + (lane >> 3)) * p.kpad_bytes + chunk * 16;
-    const long long w_step = (long long)32 * p.kpad_bytes;
-    const int in_cb = p.in_coff * SZ;
-    const int pix_b = p.in_ld * SZ;
-
-    auto stage = [&](int buf) {
-        char* la = lds + buf * BUF_BYTES + wave * 1024;
-        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-        const long long toff = (long long)(ky * p.W + kx) * pix_b + cib + in_cb;
-        const unsigned tbit = (tap < ntaps) ? (1u << tap) : 0u;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const char* src = (a_mask[i] & tbit) ? (p.in + a_off[i] + toff) : (const char*)g_zero_page;
-            GLDS16(src, la + i * 4096);
-        }
-        char* lb = lds + buf * BUF_BYTES + A_BYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < BI; ++i) GLDS16(wsrc + i * w_step, lb + i * 4096);
-        // advance to the next K-step
-        wsrc += 128;
-        cib += 128;
-        while (cib >= CinB) { cib -= CinB; ++tap; }
-    };
-
-    // ---- fragment addressing ---------------------------------------------------------------
-    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
-    const int wm0 = wm * (TM * 32), wn0 = wn * (TN * 32);
-    const int fr = lane & 31, fh = lane >> 5;
-    int a_row_off[TM], a_sw[TM], b_row_off[TN], b_sw[TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int row = wm0 + t * 32 + fr;
-        a_row_off[t] = row * 128;
-        a_sw[t] = (row >> 1) & 7;
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int row = wn0 + t * 32 + fr;
-        b_row_off[t] = A_BYTES + row * 128;
-        b_sw[t] = (row >> 1) & 7;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- main loop ---------------------------------------------------------------------------
-    stage(0);
-    __syncthreads();
-    for (int s = 0; s < p.nsteps; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < p.nsteps) stage(cur ^ 1);
-        const char* base = lds + cur * BUF_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            u32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-                af[t] = *(const u32x4*)(base + a_row_off[t] + (((2 * kk + fh) ^ a_sw[t]) << 4));
-#pragma unroll
-            for (int t = 0; t < TN; ++t)
-                bf[t] = *(const u32x4*)(base + b_row_off[t] + (((2 * kk + fh) ^ b_sw[t]) << 4));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (BF16) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        const f32x4 av = __builtin_bit_cast(f32x4, af[i]);
-                        const f32x4 bv = __builtin_bit_cast(f32x4, bf[j]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[i][j], 0, 0, 0);
-                    }
-                }
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias + activation in registers, transpose through LDS, coalesced stores ------
+    constexpr int LDC = BN + 4;
     float* ct = (float*)lds;
+    __syncthreads();                      // every wave is done reading the staging buffers
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = wn0 + j * 32 + fr;
@@ -218,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     if (p.out_f32) {
         // detection heads: Cout = 3*(5+C) is not a multiple of 8 -> scalar f32 stores, channel-coalesced
         float* outf = (float*)p.out;
-        for (int idx = tid; idx < BM * BN; idx += 256) {
+        for (int idx = tid; idx < BM * BN; idx += NT) {
             const int row = idx / BN, col = idx - row * BN;
             const int m = m0 + row, n = n0 + col;
             if (m < p.M && n < p.Cout) outf[(long long)m * p.out_ld + p.out_coff + n] = ct[row * LDC + col];
@@ -227,7 +93,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     }
 
     constexpr int CH = BN / 8;
-    for (int idx = tid; idx < BM * CH; idx += 256) {
+    constexpr int ITERS = BM * CH / NT;
+    static_assert(BM * CH % NT == 0, "epilogue geometry");
+    const int HoWo = p.Ho * p.Wo;
+    u32x4 rres[ITERS][BF16 ? 1 : 2];
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = m0 + row, n = n0 + ch * 8;
+            const bool ok = m < p.M && n < p.Cout;
+            const char* rp = p.res + ((long long)(ok ? m : 0) * p.res_ld + p.res_coff + (ok ? n : 0)) * SZ;
+            rres[it][0] = *(const u32x4*)rp;
+            if constexpr (!BF16) rres[it][1] = *(const u32x4*)(rp + 16);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NT;
         const int row = idx / CH, ch = idx - row * CH;
         const int m = m0 + row, n = n0 + ch * 8;
         if (m >= p.M || n >= p.Cout) continue;
@@ -235,13 +119,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
         f32x4 v1 = *(const f32x4*)(ct + row * LDC + ch * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (p.res) {
-            const char* rp = p.res + ((long long)m * p.res_ld + p.res_coff + n) * SZ;
             if constexpr (BF16) {
-                bf16x8 rv = *(const bf16x8*)rp;
+                const bf16x8 rv = __builtin_bit_cast(bf16x8, rres[it][0]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
             } else {
-                f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 16);
+                const f32x4 r0 = __builtin_bit_cast(f32x4, rres[it][0]), r1 = __builtin_bit_cast(f32x4, rres[it][1]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
             }
@@ -276,35 +159,506 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     }
 }
 
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_igemm_kernel(ConvK p) {
+    constexpr int SZ = BF16 ? 2 : 4;
+    constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int NT = 64 * NW;
+    constexpr int TM = BM / WARPS_M / 32;
+    constexpr int TN = BN / WARPS_N / 32;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int AI = BM / 8 / NW;   // LDS-DMA instructions per wave per K-step for A (8 rows each)
+    constexpr int BI = BN / 8 / NW;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "loader geometry");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of
+    // tiles so that the N-tiles of one M-tile (same input rows) and neighbouring M-tiles (3x3 halo)
+    // hit the same L2.  Bijective for any grid size.
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = tile / p.ntn;
+    const int nt = tile - mt * p.ntn;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int CinB = p.Cin * SZ;
+    const int ntaps = p.ksize * p.ksize;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- per-thread loader state ---------------------------------------------------------
+    // This lane fills LDS slot (row = 8g + (lane>>3), chunk' = lane&7) of row-group g = wave + NW*i;
+    // it therefore fetches logical chunk c = chunk' ^ ((row>>1)&7), identical for all its rows.
+    const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    long long a_off[AI];
+    unsigned a_mask[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = 8 * (wave + NW * i) + (lane >> 3);
+        const int m = m0 + row;
+        unsigned mask = 0;
+        long long off = 0;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int r = m - b * HoWo;
+            const int oy = r / p.Wo;
+            const int ox = r - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad;
+            const int ix0 = ox * p.stride - p.pad;
+            off = (((long long)b * p.H + iy0) * p.W + ix0) * (long long)p.in_ld * SZ;
+            for (int t = 0; t < ntaps; ++t) {
+                const int ky = (t * 11) >> 5, kx = t - ky * 3;   // ksize is 1 or 3
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+            }
+        }
+        a_off[i] = off;
+        a_mask[i] = mask;
+    }
+    int tap = 0;
+    int cib = chunk * 16;
+    while (cib >= CinB) { cib -= CinB; ++tap; }
+    const char* wsrc = p.w + (long long)(n0 + 8 * wave + (lane >> 3)) * p.kpad_bytes + chunk * 16;
+    const long long w_step = (long long)(8 * NW) * p.kpad_bytes;
+    const int in_cb = p.in_coff * SZ;
+    const int pix_b = p.in_ld * SZ;
+
+    auto stage = [&](int buf) {
+        char* la = lds + buf * BUF_BYTES + wave * 1024;
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        const long long toff = (long long)(ky * p.W + kx) * pix_b + cib + in_cb;
+        const unsigned tbit = (tap < ntaps) ? (1u << tap) : 0u;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const char* src = (a_mask[i] & tbit) ? (p.in + a_off[i] + toff) : (const char*)g_zero_page;
+            GLDS16(src, la + i * (NW * 1024));
+        }
+        char* lb = lds + buf * BUF_BYTES + A_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16(wsrc + i * w_step, lb + i * (NW * 1024));
+        // advance to the next K-step
+        wsrc += 128;
+        cib += 128;
+        while (cib >= CinB) { cib -= CinB; ++tap; }
+    };
+
+    // ---- fragment addressing ---------------------------------------------------------------
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+    const int wm0 = wm * (TM * 32), wn0 = wn * (TN * 32);
+    const int fr = lane & 31, fh = lane >> 5;
+    int a_row_off[TM], a_sw[TM], b_row_off[TN], b_sw[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int row = wm0 + t * 32 + fr;
+        a_row_off[t] = row * 128;
+        a_sw[t] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int row = wn0 + t * 32 + fr;
+        b_row_off[t] = A_BYTES + row * 128;
+        b_sw[t] = (row >> 1) & 7;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- main loop: STAGES-deep LDS ring, LDS-DMA prefetch distance STAGES-1, one barrier per step ----
+    // Iteration s: (1) wait until this thread's loads of stage s have landed, leaving the younger
+    // stages in flight (counted vmcnt); (2) workgroup barrier: every wave's share of stage s is in
+    // LDS and every wave has finished reading stage s-1; (3) refill the buffer of stage s-1 with
+    // stage s+STAGES-1; (4) fragments + MFMAs of stage s.
+    constexpr int LPS = AI + BI;      // LDS-DMA instructions per thread per stage
+#ifdef YOLO_CONV_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tbeg_ = __builtin_amdgcn_s_memtime();
+    unsigned long long tl_ = tbeg_;
+#endif
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < p.nsteps) stage(st);
+    int cur = 0;
+    STAMP(0);                          // prologue: address set-up + first stage issue
+    for (int s = 0; s < p.nsteps; ++s) {
+        if (STAGES == 3 && s + 1 < p.nsteps) {
+            if constexpr (LPS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (LPS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if constexpr (LPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (LPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr (LPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (LPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (LPS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        STAMP(1);                      // waited for own loads
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);                      // barrier
+        if (s + STAGES - 1 < p.nsteps) {
+            int nb = cur + STAGES - 1;
+            if (nb >= STAGES) nb -= STAGES;
+            stage(nb);
+        }
+        STAMP(3);                      // stage issue
+        const char* base = lds + cur * BUF_BYTES;
+        // all fragment reads of the K-step are issued up front: the MFMAs start as soon as their
+        // operands land (counted lgkmcnt) instead of exposing one LDS latency per 16-deep k slice
+        u32x4 af[4][TM], bf[4][TN];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                af[kk][t] = *(const u32x4*)(base + a_row_off[t] + (((2 * kk + fh) ^ a_sw[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                bf[kk][t] = *(const u32x4*)(base + b_row_off[t] + (((2 * kk + fh) ^ b_sw[t]) << 4));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (BF16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4 av = __builtin_bit_cast(f32x4, af[kk][i]);
+                        const f32x4 bv = __builtin_bit_cast(f32x4, bf[kk][j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+#ifdef YOLO_CONV_STAMPS
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]));
+        STAMP(4);                      // fragment reads + MFMA issue
+#endif
+    }
+    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
+#ifdef YOLO_CONV_STAMPS
+    STAMP(6);                          // residual + stores
+    if ((blockIdx.x & 63) == 0 && tid == 0 && (blockIdx.x >> 6) < 64) {
+        unsigned long long* o = g_stamps + (blockIdx.x >> 6) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = st_[i];
+        o[7] = tl_ - tbeg_;
+    }
+#endif
+}
+
+#ifdef YOLO_CONV_STAMPS
+extern "C" int yolo_debug_read_stamps(unsigned long long* host, int n) {
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_stamps)) != hipSuccess) return YOLO_ERR_HIP;
+    if (hipDeviceSynchronize() != hipSuccess) return YOLO_ERR_HIP;
+    if (hipMemcpy(host, dptr, sizeof(unsigned long long) * (size_t)(n < 512 ? n : 512), hipMemcpyDeviceToHost) != hipSuccess) return YOLO_ERR_HIP;
+    return YOLO_OK;
+}
+#endif
+
+// ---- 3x3 stride-1 convolution with an LDS-resident input patch ("halo" kernel) -------------------
+// The im2col kernel above re-loads every input pixel once per tap (9x) and is bound by the global->LDS
+// fill rate (measured ~900 cycles per 32 KB stage, the MFMAs of that stage need 512).  Here a tile of BM
+// consecutive output pixels (flattened b,y,x) stages, per 128-byte channel chunk, the BM + 2W + 2
+// consecutive input pixel rows it touches ONCE; the nine taps are shifted fragment reads of that patch
+// (patch row = output row + ky*W + kx).  Taps that fall outside the image (where the flattened
+// neighbour is a real pixel of the previous/next row or image) are zeroed in registers with a per-row
+// 9-bit mask.  Only the [BN x 128 B] weight tile is loaded per tap.  Global->LDS traffic per FLOP drops
+// ~2.4x (BM=256) against im2col at the same tile.
+// K order of the packed weights stays (ky,kx,ci); the loop order here is (ci-chunk, tap).
 template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N>
-static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    constexpr int loop_bytes = 2 * (BM + BN) * 128;
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(ConvK p, int prows) {
+    constexpr int SZ = BF16 ? 2 : 4;
+    constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int NT = 64 * NW;
+    constexpr int TM = BM / WARPS_M / 32;
+    constexpr int TN = BN / WARPS_N / 32;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int BI = BN / 8 / NW;
+    static_assert(BN % (8 * NW) == 0 && NW % 2 == 0 && BI >= 1, "loader geometry");
+
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = tile / p.ntn;
+    const int nt = tile - mt * p.ntn;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int W = p.W;
+    const int CinB = p.Cin * SZ;
+    const int nchunks = CinB >> 7;
+    const int patch_bytes = prows * 128;          // prows: BM + 2W + 2 rounded up to 8
+    char* const patch0 = lds;
+    char* const bbuf0 = lds + (nchunks > 1 ? 2 : 1) * patch_bytes;   // one patch buffer suffices for one chunk
+    char* const zrow = bbuf0 + 2 * B_BYTES;       // 128 zero bytes: source of out-of-image taps
+    if (tid < 32) ((unsigned*)zrow)[tid] = 0u;    // ordered before the first fragment read by the loop's barrier
+
+    // ---- loader state ----------------------------------------------------------------------------
+    const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const int ngroups = prows >> 3;               // 8-row LDS-DMA pieces of the patch
+    // Addresses are a wave-uniform 64-bit base (SALU) + a 32-bit per-lane offset, so a piece costs almost
+    // no VALU.  Patch rows outside the tensor are only ever referenced by masked taps: they are clamped
+    // into range instead of zero-filled (the mask redirects those fragment reads to `zrow`).
+    const int qlane = m0 - W - 1 + (lane >> 3);   // input pixel (flattened) of this lane's row in piece 0
+    const unsigned pix_b = (unsigned)(p.in_ld * SZ);
+    const char* const in_base = p.in + (long long)p.in_coff * SZ;
+    const char* const w_base = p.w + (long long)n0 * p.kpad_bytes;
+    unsigned w_off[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) w_off[i] = (unsigned)(8 * (wave + NW * i) + (lane >> 3)) * (unsigned)p.kpad_bytes + chunk * 16;
+
+    // patch piece `slot` of this wave for channel chunk c -> patch buffer c&1
+    auto load_patch_piece = [&](int c, int slot) {
+        const int g = wave + NW * slot;
+        if (g < ngroups) {
+            int q = qlane + 8 * g;
+            q = q < 0 ? 0 : (q >= p.M ? p.M - 1 : q);
+            const unsigned off = (unsigned)q * pix_b + chunk * 16;
+            GLDS16(in_base + c * 128 + off, patch0 + (c & 1) * patch_bytes + g * 1024);
+        }
+    };
+    // weight tile of (chunk c, tap t) -> weight buffer `buf`
+    auto load_b = [&](int c, int t, int buf) {
+        const char* src = w_base + ((long long)t * CinB + c * 128);
+        char* lb = bbuf0 + buf * B_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16(src + w_off[i], lb + i * (NW * 1024));
+    };
+    const int slots = (ngroups + NW - 1) / NW;    // patch pieces per wave per chunk
+
+    // ---- fragment addressing -----------------------------------------------------------------------
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+    const int wm0 = wm * (TM * 32), wn0 = wn * (TN * 32);
+    const int fr = lane & 31, fh = lane >> 5;
+    unsigned a_mask[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int m = m0 + wm0 + t * 32 + fr;
+        unsigned mask = 0;
+        if (m < p.M) {
+            const int r = m % (p.H * W);
+            const int y = r / W, x = r - y * W;
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) {
+                const int iy = y + tt / 3 - 1, ix = x + tt % 3 - 1;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < W) mask |= 1u << tt;
+            }
+        }
+        a_mask[t] = mask;
+    }
+    int b_row_off[TN], b_sx[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int row = wn0 + t * 32 + fr;
+        b_row_off[t] = row * 128;
+        b_sx[t] = (((row >> 1) & 7) ^ fh) << 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#ifdef YOLO_CONV_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tbeg_ = __builtin_amdgcn_s_memtime();
+    unsigned long long tl_ = tbeg_;
+#endif
+    // ---- prologue: whole patch of chunk 0 + weight tile (0,0) ----------------------------------------
+    for (int sl = 0; sl < slots; ++sl) load_patch_piece(0, sl);
+    load_b(0, 0, 0);
+
+    // ---- main loop over (chunk c, tap t); one barrier per step ----------------------------------------
+    // Loads issued during step s (next weight tile, 1/9 of the next chunk's patch) must have landed by
+    // the barrier that opens step s+1; the buffers they overwrite were last read in step s-1.
+    int bcur = 0;
+    STAMP(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const char* patch = patch0 + (c & 1) * patch_bytes;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(2);
+            // prefetch
+            if (t < 8) load_b(c, t + 1, bcur ^ 1);
+            else if (c + 1 < nchunks) load_b(c + 1, 0, bcur ^ 1);
+            if (c + 1 < nchunks)
+                for (int sl = t; sl < slots; sl += 9) load_patch_piece(c + 1, sl);
+            STAMP(3);
+            // fragments of this tap
+            const int ky = (t * 11) >> 5, kx = t - ky * 3;
+            const int shift = ky * W + kx;
+            const char* bbase = bbuf0 + bcur * B_BYTES;
+            u32x4 af[4][TM], bf[4][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int prow = wm0 + i * 32 + fr + shift;
+                const bool ok = (a_mask[i] >> t) & 1;
+                const char* rowp = ok ? patch + prow * 128 : zrow;     // masked tap: read zeros
+                const int sx = (((prow >> 1) & 7) ^ fh) << 4;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) af[kk][i] = *(const u32x4*)(rowp + ((kk << 5) ^ sx));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[kk][j] = *(const u32x4*)(bbase + b_row_off[j] + ((kk << 5) ^ b_sx[j]));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (BF16) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
+                        } else {
+                            const f32x4 av = __builtin_bit_cast(f32x4, af[kk][i]);
+                            const f32x4 bv = __builtin_bit_cast(f32x4, bf[kk][j]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+            bcur ^= 1;
+#ifdef YOLO_CONV_STAMPS
+            asm volatile("s_nop 0" :: "v"(acc[0][0][0]));
+            STAMP(4);
+#endif
+        }
+    }
+    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
+#ifdef YOLO_CONV_STAMPS
+    STAMP(6);
+    if ((blockIdx.x & 63) == 0 && tid == 0 && (blockIdx.x >> 6) < 64) {
+        unsigned long long* o = g_stamps + (blockIdx.x >> 6) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = st_[i];
+        o[7] = tl_ - tbeg_;
+    }
+#endif
+}
+
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N>
+static int launch_halo(const ConvK& k, hipStream_t stream) {
+    const int prows = (int)align_up((size_t)(BM + 2 * k.W + 2), 8);
+    const int nchunks = k.Cin * (BF16 ? 2 : 4) / 128;
+    const int loop_bytes = (nchunks > 1 ? 2 : 1) * prows * 128 + 2 * BN * 128 + 128;
     constexpr int epi_bytes = BM * (BN + 4) * 4;
-    constexpr int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
-    auto fn = conv_igemm_kernel<BF16, BM, BN, WARPS_M, WARPS_N>;
+    const int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
+    YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 halo: W=%d needs %d bytes of LDS", k.W, lds_bytes);
+    YOLO_REQUIRE((long long)k.M * k.in_ld * (BF16 ? 2 : 4) < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 halo: input larger than 4 GiB");
+    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N>;
     static bool attr_done[16] = {false};
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 16 && !attr_done[dev]) {
-        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_done[dev] = true;
-    } else if (dev >= 16) {
-        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (dev >= 16 || !attr_done[dev]) {
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev < 16) attr_done[dev] = true;
     }
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(256), lds_bytes, stream, kk);
+    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
 }
 
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES>
+static int launch_cfg(const ConvK& k, hipStream_t stream) {
+    constexpr int loop_bytes = STAGES * (BM + BN) * 128;
+    constexpr int epi_bytes = BM * (BN + 4) * 4;
+    constexpr int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    auto fn = conv_igemm_kernel<BF16, BM, BN, WARPS_M, WARPS_N, STAGES>;
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    YOLO_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_done[dev]) {
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        if (dev < 16) attr_done[dev] = true;
+    }
+    ConvK kk = k;
+    kk.ntm = (k.M + BM - 1) / BM;
+    kk.ntn = (k.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+// Tile configurations.  YOLO_CONV_CFG=<id> (environment, read once) forces one for experiments.
 template <bool BF16>
 static int launch_dtype(const ConvK& k, hipStream_t stream) {
-    // Tile choice: widest N tile the layer fills; tall M tile when N is narrow (early layers).
-    if (k.Cout <= 32) return launch_cfg<BF16, 256, 32, 4, 1>(k, stream);
-    if (k.Cout <= 64) return launch_cfg<BF16, 256, 64, 4, 1>(k, stream);
-    return launch_cfg<BF16, 128, 128, 2, 2>(k, stream);
+    static const int forced = [] { const char* e = getenv("YOLO_CONV_CFG"); return e ? atoi(e) : -1; }();
+    int cfg = forced;
+    const int sz = BF16 ? 2 : 4;
+    const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32;
+    if (cfg >= 20 && !halo_ok) cfg = -1;
+    if (cfg >= 0 && cfg < 20 && k.Cout <= 64) cfg = -1;
+    if (cfg < 0) {
+        // measured per layer shape at batch 64 (scripts/bench_layer.py, profiles/): the LDS-resident patch
+        // kernel wins on every 3x3 stride-1 layer it fits; small grids (many tiles of few pixels) prefer
+        // 128x128 tiles at 2 blocks/CU, large grids 256x128 at 8 waves.
+        const int prows256 = 256 + 2 * k.W + 2 + 7;
+        if (k.Cout <= 32) cfg = 10;
+        else if (k.Cout <= 64) cfg = 11;
+        else if (halo_ok && k.W <= 32) cfg = 21;
+        else if (halo_ok && 2 * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 20;
+        else if (halo_ok && k.Cin * sz == 128 && prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 20;
+        else cfg = 0;
+    }
+    switch (cfg) {
+        case 0: return launch_cfg<BF16, 128, 128, 2, 2, 2>(k, stream);     // 2 blocks/CU
+        case 1: return launch_cfg<BF16, 256, 128, 4, 2, 3>(k, stream);     // 8 waves, 3-stage ring, 1 block/CU
+        case 2: return launch_cfg<BF16, 128, 128, 2, 2, 3>(k, stream);     // 4 waves, 3-stage ring, 1 block/CU
+        case 3: return launch_cfg<BF16, 128, 256, 2, 4, 3>(k, stream);
+        case 4: return launch_cfg<BF16, 256, 128, 4, 2, 2>(k, stream);
+        case 20: return launch_halo<BF16, 256, 128, 4, 2>(k, stream);
+        case 21: return launch_halo<BF16, 128, 128, 2, 2>(k, stream);
+        case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
+        case 11: return launch_cfg<BF16, 256, 64, 4, 1, 2>(k, stream);
+        default: break;
+    }
+    set_error("conv: unknown tile configuration %d", cfg);
+    return YOLO_ERR_ARG;
 }
 
 int launch_conv_igemm(int dtype, const ConvLaunch& p, hipStream_t stream) {

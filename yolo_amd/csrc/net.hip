@@ -64,7 +64,18 @@ static int pack_conv(ConvParams& L, WAt w_at, const float* p0, const float* p1, 
     const int sz = L.dtype == YOLO_DTYPE_BF16 ? 2 : 4;
     size_t wbytes;
     std::vector<char> host;
-    if (L.stem) {
+    if (L.stem && sz == 2) {
+        // MFMA stem: [Cout][K pad 32] bf16, k = (ky*3+kx)*3 + c
+        L.npad = co;
+        L.kpad_bytes = 64;
+        wbytes = (size_t)co * 64;
+        host.assign(wbytes, 0);
+        for (int n = 0; n < co; ++n)
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx)
+                    for (int c = 0; c < ci; ++c)
+                        ((uint16_t*)host.data())[n * 32 + (ky * k + kx) * ci + c] = f32_to_bf16_rne(w_at(n, c, ky, kx) * scale[n]);
+    } else if (L.stem) {
         L.npad = co;
         L.kpad_bytes = 0;
         wbytes = (size_t)k * k * ci * co * 4;
@@ -479,4 +490,50 @@ extern "C" int yolo_conv_forward(YoloConv* c, const float* in, int B, int H, int
     if (rc != YOLO_OK) return rc;
     if (bf && !head) return launch_cast_bf16_to_f32(ws + in_b, out, (size_t)B * ho * wo * L.cout, stream);
     return YOLO_OK;
+}
+
+// Measurement aid (no counterpart in the reference): run one conv layer `iters` times on device
+// buffers of the layer's own dtype (allocated and freed here, random contents) and report the average
+// kernel time from HIP events.  Used by scripts/bench_layer.py to tune tile shapes per layer.
+extern "C" int yolo_conv_benchmark(YoloConv* c, int B, int H, int W, int with_residual, int iters, float* avg_ms) {
+    YOLO_REQUIRE(c && avg_ms && B > 0 && H > 0 && W > 0 && iters > 0, YOLO_ERR_ARG, "conv_benchmark: bad argument");
+    const ConvParams& L = c->p;
+    const int sz = L.dtype == YOLO_DTYPE_BF16 ? 2 : 4;
+    const int pad = (L.k - 1) / 2;
+    const int ho = (H + 2 * pad - L.k) / L.stride + 1, wo = (W + 2 * pad - L.k) / L.stride + 1;
+    const size_t in_bytes = (size_t)B * H * W * L.cin * (L.stem ? 4 : sz);
+    const size_t out_bytes = (size_t)B * ho * wo * align_up((size_t)L.cout, 8) * 4;
+    void *in = nullptr, *out = nullptr, *res = nullptr;
+    YOLO_HIP_CHECK(hipMalloc(&in, in_bytes));
+    YOLO_HIP_CHECK(hipMalloc(&out, out_bytes));
+    YOLO_HIP_CHECK(hipMalloc(&res, out_bytes));
+    {   // random finite contents (bf16 pattern 0x3dxx..0x3fxx / small f32)
+        std::vector<uint16_t> h(in_bytes / 2);
+        uint32_t s = 12345u;
+        for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3c00u + ((s >> 16) & 0x3ffu) + ((s >> 3) & 0x8000u)); }
+        YOLO_HIP_CHECK(hipMemcpy(in, h.data(), in_bytes / 2 * 2, hipMemcpyHostToDevice));
+        YOLO_HIP_CHECK(hipMemset(res, 0, out_bytes));
+    }
+    ConvLaunch p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.in = in; p.in_ld = L.cin; p.out = out; p.out_ld = L.cout;
+    if (L.cout % 8) p.out_f32 = 1;
+    if (with_residual && !p.out_f32) { p.res = res; p.res_ld = L.cout; }
+    hipEvent_t e0, e1;
+    YOLO_HIP_CHECK(hipEventCreate(&e0));
+    YOLO_HIP_CHECK(hipEventCreate(&e1));
+    int rc = YOLO_OK;
+    for (int i = 0; i < 3 && rc == YOLO_OK; ++i) rc = run_conv(L, p, nullptr);
+    if (rc == YOLO_OK) {
+        (void)hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters && rc == YOLO_OK; ++i) rc = run_conv(L, p, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) != hipSuccess) { set_error("conv_benchmark: sync failed"); rc = YOLO_ERR_HIP; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_ms = ms / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(in); (void)hipFree(out); (void)hipFree(res);
+    return rc;
 }

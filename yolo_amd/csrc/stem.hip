@@ -66,16 +66,96 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
     }
 }
 
+// bf16 path: the same layer on MFMA.  K = 27 is padded to 32: two v_mfma_f32_32x32x16_bf16 per 32
+// pixels x 32 channels.  A lane (pixel = lane&31, half = lane>>5) gathers its 16 im2col values
+// k = 16m + 8*half + j straight from the f32 image (k = (ky*3+kx)*3 + c; the three taps of one input
+// row are 9 contiguous floats), rounds them to bf16 and feeds the MFMA; weights [32 cout][32 k] bf16
+// stay in registers.  The 32x32 f32 result is transposed through a wave-private LDS tile so that
+// every lane stores 32 contiguous bytes (16 channels of one pixel): 2 KiB contiguous per wave.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in, const u32x4* __restrict__ w,
+                                                        const float* __restrict__ bias, char* __restrict__ out,
+                                                        int B, int H, int W, int out_ld, int out_coff, int leaky) {
+    __shared__ float tile[4][32 * 33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    float* tl = tile[wave];
+    // weight fragments: B[k = 16m + 8h + j][cout = fr]  <-  w[cout][k]
+    const bf16x8 wf0 = __builtin_bit_cast(bf16x8, w[fr * 4 + fh]);
+    const bf16x8 wf1 = __builtin_bit_cast(bf16x8, w[fr * 4 + 2 + fh]);
+    // per-lane im2col tables (invariant over pixels)
+    int koff[2][8];
+    unsigned need[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kq = 16 * m + 8 * fh + j;
+            const int ky = kq / 9, rem = kq - ky * 9, kx = rem / 3;
+            koff[m][j] = (ky - 1) * W * 3 + rem - 3;
+            need[m][j] = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u) | (kq >= 27 ? 16u : 0u);
+        }
+    const float bv = bias[fr];
+    const long long npix = (long long)B * H * W;
+    const long long ngroups = (npix + 31) >> 5;
+    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long long)gridDim.x * 4) {
+        const long long m = grp * 32 + fr;
+        const bool pv = m < npix;
+        const int x = (int)(m % W);
+        const int y = (int)((m / W) % H);
+        const unsigned lack = (y > 0 ? 0u : 1u) | (y < H - 1 ? 0u : 2u) | (x > 0 ? 0u : 4u) | (x < W - 1 ? 0u : 8u) | 16u;
+        const float* base = in + m * 3;
+        bf16x8 a0, a1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok0 = pv && (need[0][j] & lack) == 0;
+            const bool ok1 = pv && (need[1][j] & lack) == 0;
+            a0[j] = (__bf16)(ok0 ? base[koff[0][j]] : 0.f);
+            a1[j] = (__bf16)(ok1 ? base[koff[1][j]] : 0.f);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf1, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            float v = acc[r] + bv;
+            if (leaky) v = 0.55f * v + 0.45f * __builtin_fabsf(v);
+            tl[row * 33 + fr] = v;
+        }
+        const int pr = lane >> 1, c0 = (lane & 1) * 16;
+        const long long mo = grp * 32 + pr;
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o0[e] = (__bf16)tl[pr * 33 + c0 + e];
+            o1[e] = (__bf16)tl[pr * 33 + c0 + 8 + e];
+        }
+        if (mo < npix) {
+            char* op = out + (mo * out_ld + out_coff + c0) * 2;
+            *(bf16x8*)op = o0;
+            *(bf16x8*)(op + 16) = o1;
+        }
+    }
+}
+
 int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream) {
     YOLO_REQUIRE(p.Cin == 3 && p.ksize == 3 && p.stride == 1 && p.Cout == 32 && p.in_ld == 3 && p.in_coff == 0,
                  YOLO_ERR_UNSUPPORTED, "stem: only 3x3 s1 3->32 on a dense RGB image is implemented");
     YOLO_REQUIRE(p.out_ld % 8 == 0 && p.out_coff % 8 == 0, YOLO_ERR_SHAPE, "stem: output stride");
     const long long npix = (long long)p.B * p.H * p.W;
     const unsigned grid = (unsigned)((npix + 255) / 256);
-    if (dtype == YOLO_DTYPE_BF16)
-        hipLaunchKernelGGL((stem_kernel<true, 32>), dim3(grid), dim3(256), 0, stream, (const float*)p.in,
-                           (const float*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
-    else
+    if (dtype == YOLO_DTYPE_BF16) {
+        const long long ngroups = (npix + 31) / 32;
+        long long g = (ngroups + 3) / 4;
+        if (g > 256 * 16) g = 256 * 16;
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.in,
+                           (const u32x4*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
+    } else
         hipLaunchKernelGGL((stem_kernel<false, 32>), dim3(grid), dim3(256), 0, stream, (const float*)p.in,
                            (const float*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
     YOLO_HIP_CHECK(hipGetLastError());
