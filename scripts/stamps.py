@@ -11,7 +11,7 @@ from yolo_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "yolo_amd", "lib", "libyolo_hip_stamps.so")
 L = _lib.lib()
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
-names = ["prologue", "wait_vmcnt", "barrier", "stage_issue", "frag+mfma", "acc->lds", "stores", "total"]
+names = ["res+stores", "wait_vmcnt", "barrier", "stage_issue", "frag+mfma", "epi: sync1", "epi: acc->lds", "epi: sync2"]
 import importlib
 SH = None
 src = open(os.path.join(ROOT, "scripts", "bench_layer.py")).read()
@@ -42,6 +42,8 @@ for idx in [int(x) for x in a.only.split(",")]:
                 print("   %-12s %10.0f cycles  (%5.1f%%)   %.0f / step" % (n_, v, 100 * v / med[7], v / nsteps))
         continue
     med = np.median(st, axis=0)
+    tot = med.sum()
     for n_, v in zip(names, med):
         per = v / nsteps if n_ in ("wait_vmcnt", "barrier", "stage_issue", "frag+mfma") else v
-        print("   %-12s %10.0f cycles  (%5.1f%%)%s" % (n_, v, 100 * v / med[7], "   %.0f / step" % per if per != v else ""))
+        print("   %-14s %10.0f cycles  (%5.1f%%)%s" % (n_, v, 100 * v / tot, "   %.0f / step" % per if per != v else ""))
+    print("   %-14s %10.0f cycles" % ("sum (no prologue)", tot))

@@ -60,11 +60,16 @@ struct ConvK {
 // stores, no LDS - was measured 15-25 % SLOWER per layer: 32 partial lines per store instruction.)
 template <bool BF16, int BM, int BN, int TM, int TN, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], char* lds, int m0, int n0,
-                                              int wm0, int wn0, int tid, int fr, int fh) {
+                                              int wm0, int wn0, int tid, int fr, int fh
+#ifdef YOLO_CONV_STAMPS
+                                              , unsigned long long (&st_)[8], unsigned long long& tl_
+#endif
+                                              ) {
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int LDC = BN + 4;
     float* ct = (float*)lds;
     __syncthreads();                      // every wave is done reading the staging buffers
+    STAMP(5);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = wn0 + j * 32 + fr;
@@ -79,7 +84,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
                 ct[row * LDC + col] = v;
             }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(6);
     __syncthreads();
+    STAMP(7);
 
     if (p.out_f32) {
         // detection heads: Cout = 3*(5+C) is not a multiple of 8 -> scalar f32 stores, channel-coalesced
@@ -356,13 +364,20 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_igemm_kernel(Conv
         STAMP(4);                      // fragment reads + MFMA issue
 #endif
     }
+    #ifdef YOLO_CONV_STAMPS
+    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
+#else
     conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
+#endif
 #ifdef YOLO_CONV_STAMPS
-    STAMP(6);                          // residual + stores
+    {
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+        st_[0] = t_ - tl_;             // residual + stores (the prologue slot is reused)
+        tl_ = t_;
+    }
     if ((blockIdx.x & 63) == 0 && tid == 0 && (blockIdx.x >> 6) < 64) {
         unsigned long long* o = g_stamps + (blockIdx.x >> 6) * 8;
-        for (int i = 0; i < 7; ++i) o[i] = st_[i];
-        o[7] = tl_ - tbeg_;
+        for (int i = 0; i < 8; ++i) o[i] = st_[i];
     }
 #endif
 }
@@ -566,13 +581,20 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
 #endif
         }
     }
+    #ifdef YOLO_CONV_STAMPS
+    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
+#else
     conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
+#endif
 #ifdef YOLO_CONV_STAMPS
-    STAMP(6);
+    {
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+        st_[0] = t_ - tl_;
+        tl_ = t_;
+    }
     if ((blockIdx.x & 63) == 0 && tid == 0 && (blockIdx.x >> 6) < 64) {
         unsigned long long* o = g_stamps + (blockIdx.x >> 6) * 8;
-        for (int i = 0; i < 7; ++i) o[i] = st_[i];
-        o[7] = tl_ - tbeg_;
+        for (int i = 0; i < 8; ++i) o[i] = st_[i];
     }
 #endif
 }
@@ -632,18 +654,19 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
     const int sz = BF16 ? 2 : 4;
     const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32;
     if (cfg >= 20 && !halo_ok) cfg = -1;
-    if (cfg >= 0 && cfg < 20 && k.Cout <= 64) cfg = -1;
+    if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
+    if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
     if (cfg < 0) {
         // measured per layer shape at batch 64 (scripts/bench_layer.py, profiles/): the LDS-resident patch
         // kernel wins on every 3x3 stride-1 layer it fits; small grids (many tiles of few pixels) prefer
         // 128x128 tiles at 2 blocks/CU, large grids 256x128 at 8 waves.
         const int prows256 = 256 + 2 * k.W + 2 + 7;
+        const int patch_bufs = k.Cin * sz > 128 ? 2 : 1;
         if (k.Cout <= 32) cfg = 10;
-        else if (k.Cout <= 64) cfg = 11;
-        else if (halo_ok && k.W <= 32) cfg = 21;
-        else if (halo_ok && 2 * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 20;
-        else if (halo_ok && k.Cin * sz == 128 && prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 20;
-        else cfg = 0;
+        else if (k.Cout <= 64) cfg = k.ksize == 1 ? 14 : 12;
+        else if (halo_ok && k.W <= 32) cfg = 24;
+        else if (halo_ok && patch_bufs * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 26;
+        else cfg = 5;
     }
     switch (cfg) {
         case 0: return launch_cfg<BF16, 128, 128, 2, 2, 2>(k, stream);     // 2 blocks/CU
@@ -653,6 +676,14 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 4: return launch_cfg<BF16, 256, 128, 4, 2, 2>(k, stream);
         case 20: return launch_halo<BF16, 256, 128, 4, 2>(k, stream);
         case 21: return launch_halo<BF16, 128, 128, 2, 2>(k, stream);
+        case 5: return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);     // 8 waves, 2 blocks/CU
+        case 6: return launch_cfg<BF16, 128, 128, 2, 4, 2>(k, stream);
+        case 24: return launch_halo<BF16, 128, 128, 4, 2>(k, stream);      // 8 waves, 2 blocks/CU
+        case 25: return launch_halo<BF16, 128, 128, 2, 4>(k, stream);
+        case 26: return launch_halo<BF16, 256, 128, 8, 2>(k, stream);      // 16 waves, 1 block/CU
+        case 27: return launch_halo<BF16, 256, 128, 4, 4>(k, stream);
+        case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
+        case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
         case 11: return launch_cfg<BF16, 256, 64, 4, 1, 2>(k, stream);
         default: break;
