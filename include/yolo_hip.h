@@ -114,6 +114,34 @@ int yolo_nms(const float* boxes, const float* scores, int B, int n, int class_nu
              int32_t* out_labels, int32_t* out_index, int32_t* out_counts, void* workspace,
              size_t workspace_bytes, void* stream);
 
+/* ---- YOLOv2 (config 4).  yolo2_net_create/forward replace yolo_v2.build_networks + conv_layer + pooling_layer +
+ * reorg (yolo_v2/yolo/yolo_v2.py:32-113).  vars: HOST float32, the TF variables concatenated in creation order per
+ * conv (yolo_v2.py:75-83): weight [k,k,cin,cout], biases, then (batch-norm layers) scale, shift, rolling_mean,
+ * rolling_variance.  images [B,H,W,3] f32 in [-1,1] (Detector.py:39) -> logits [B,H/32,W/32,box_per_cell*(5+C)].
+ * Workspace size: yolo_net_workspace_bytes; destroy with yolo_net_destroy. */
+int yolo2_net_create(int num_class, int box_per_cell, int dtype, const float* vars, size_t n_floats, YoloNet** out);
+int yolo2_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
+                      size_t workspace_bytes, float* logits, void* stream);
+/* One YOLOv2 layer: replaces conv_layer (yolo_v2.py:73-89): SAME conv -> batch_normalization(mean, variance, shift,
+ * scale, 1e-5) -> + biases -> max(0.1x, x); batch_norm == 0: conv + biases.  All parameter pointers HOST f32;
+ * weight_hwio [k,k,cin,cout].  Run / size / free with yolo_conv_forward / yolo_conv_workspace_bytes / yolo_conv_destroy. */
+int yolo2_conv_create(int dtype, int cin, int cout, int ksize, int batch_norm, const float* weight_hwio,
+                      const float* biases, const float* scale, const float* shift, const float* mean,
+                      const float* variance, YoloConv** out);
+/* 2x2 stride-2 max-pool on NHWC f32 (pooling_layer, yolo_v2.py:91-94). */
+int yolo_maxpool2x2(const float* in, int B, int H, int W, int C, float* out, void* stream);
+/* Space-to-depth [B,H,W,C] -> [B,H/2,W/2,4C], channel block (dy*2+dx)*C (reorg, yolo_v2.py:97-113). */
+int yolo_reorg2x(const float* in, int B, int H, int W, int C, float* out, void* stream);
+/* yolo2_decode + yolo2_nms replace Detector.calc_output / get_boxes / calc_iou (yolo_v2/Detector.py:51-115).
+ * anchors: HOST double[2*NB], widths then heights (yolo_v2/yolo/config.py:13).  boxes are float64 (cx,cy,w,h) in
+ * input pixels, probs float32 = softmax(classes) * sigmoid(conf), exactly the reference's numpy dtypes. */
+int yolo2_decode(const float* logits, int B, int S, int NB, int C, int image_size, const double* anchors,
+                 double* boxes, float* probs, void* stream);
+size_t yolo2_nms_workspace_bytes(int B, int n, int C);
+int yolo2_nms(const double* boxes, const float* probs, int B, int n, int C, float threshold, double iou_thresh,
+              int max_det, int32_t* out_counts, int32_t* out_cls, double* out_boxes, float* out_probs,
+              int32_t* out_flat, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,9 @@ G2  decode          : reference `predict_transform` (002/util.py) output [1, n, 
 G3  cpu_nms/py_nms  : reference yolo_v3/utils/nms_utils.py numpy functions on seeded boxes.
                       (`tensorflow` is stubbed with an empty module: only `gpu_nms` touches it.)
 G3b calc_iou        : reference yolo_v3/utils/eval_utils.py:7-21.
+G4  v2 decode + NMS : reference yolo_v2/Detector.py `calc_output` (:51-89, with get_boxes / calc_iou) called on a
+                      bare `Detector.__new__` object whose attributes come from the reference's yolo/config.py
+                      (`tensorflow` and `cv2` stubbed with empty modules: only __init__/detect/draw touch them).
 """
 import os
 import sys
@@ -148,9 +151,48 @@ def gen_nms():
     print("G3b", iou.shape, iou.dtype)
 
 
+def gen_v2_decode():
+    sys.modules["tensorflow"] = types.ModuleType("tensorflow")
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    for m in [k for k in sys.modules if k == "yolo" or k.startswith("yolo.") or k == "Detector"]:
+        del sys.modules[m]
+    sys.path.insert(0, os.path.join(REF, "yolo_v2"))
+    import Detector as D                                   # reference module
+    import yolo.config as cfg                              # reference constants
+    det = D.Detector.__new__(D.Detector)                   # no tf.Session: calc_output is pure numpy
+    det.classes = cfg.CLASSES
+    det.num_classes = len(cfg.CLASSES)
+    det.image_size = cfg.IMAGE_SIZE
+    det.cell_size = cfg.CELL_SIZE
+    det.box_per_cell = cfg.BOX_PRE_CELL
+    det.threshold = cfg.THRESHOLD
+    det.anchor = cfg.ANCHOR
+    rng = np.random.default_rng(41)
+    flat = {}
+
+    def logits(conf_bias, cls_scale, wh_scale=0.4):
+        t = rng.normal(0, 1, (1, 13, 13, 5, 25)).astype(np.float32)
+        t[..., 2:4] *= wh_scale
+        t[..., 4] += conf_bias
+        t[..., 5:] *= cls_scale
+        return t.reshape(1, 13, 13, 125)
+
+    for name, t in (("a", logits(-2.0, 3.0)), ("b", logits(1.5, 4.0)), ("c", logits(0.0, 2.5, 0.8)),
+                    ("empty", logits(-8.0, 1.0))):
+        res = det.calc_output(t.copy())
+        flat[name + "/logits"] = t
+        flat[name + "/cls"] = np.asarray([cfg.CLASSES.index(r[0]) for r in res], np.int32)
+        flat[name + "/boxes"] = np.asarray([r[1:5] for r in res], np.float64).reshape(-1, 4)
+        flat[name + "/probs"] = np.asarray([r[5] for r in res], np.float32)
+        print("G4", name, len(res))
+    np.savez_compressed(os.path.join(OUT, "g4_v2_decode.npz"), **flat)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["conv", "nms"]
+    which = sys.argv[1:] or ["conv", "nms", "v2"]
+    if "v2" in which:
+        gen_v2_decode()
     if "nms" in which:
         gen_nms()
     if "conv" in which:

@@ -9,7 +9,7 @@ from conftest import ROOT
 def _declared():
     src = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(yolo_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(yolo2?_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_exported_and_bound():
@@ -35,6 +35,10 @@ def test_argument_errors_without_gpu():
     assert rc == -1 and b"null" in L.yolo_last_error()
     rc = L.yolo_decode(None, None, None, 1, 416, 416, 80, None, None, None, None, None, None)
     assert rc == -1
+    assert L.yolo2_nms_workspace_bytes(2, 845, 20) >= 2 * 845 * 20 * 8
+    assert L.yolo2_decode(None, 1, 13, 5, 20, 416, None, None, None, None) == -1
+    assert L.yolo_maxpool2x2(None, 1, 4, 4, 8, None, None) == -1
+    assert L.yolo_reorg2x(None, 1, 4, 4, 8, None, None) == -1
 
 
 def test_product_does_not_import_oracle():

@@ -111,3 +111,34 @@ def test_calc_iou_fixture_consistency(oracle):
     ap = (p[:, 2] - p[:, 0]) * (p[:, 3] - p[:, 1])
     at = (t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])
     np.testing.assert_allclose(inter / (ap[:, None] + at[None] - inter + 1e-10), g["iou"], rtol=1e-5, atol=1e-6)
+
+
+# ---- YOLOv2 (config 4) -------------------------------------------------------------------------
+def test_v2_calc_output_matches_reference():
+    """G4: oracle decode + class-agnostic NMS == reference yolo_v2/Detector.py calc_output (bit-exact)."""
+    from oracle import yolo2_oracle as O2
+    cases = _cases(load_golden("g4_v2_decode.npz"))
+    assert set(cases) == {"a", "b", "c", "empty"}
+    for name, d in cases.items():
+        boxes, probs = O2.decode(d["logits"])
+        assert boxes.dtype == np.float64 and probs.dtype == np.float32
+        cls, bx, pr, flat = O2.nms_from_decoded(boxes, probs)
+        np.testing.assert_array_equal(cls, d["cls"], err_msg=name)
+        np.testing.assert_array_equal(bx, d["boxes"].reshape(-1, 4), err_msg=name)
+        np.testing.assert_array_equal(pr, d["probs"], err_msg=name)
+        res = O2.calc_output(d["logits"])
+        assert [r[0] for r in res] == [O2.CLASSES[c] for c in d["cls"]]
+    assert len(cases["empty"]["cls"]) == 0 and len(cases["b"]["cls"]) > 100
+
+
+def test_v2_network_restatement_shapes_and_reorg():
+    """yolo_v2.py:97-113 channel order of reorg and the [reorg, net24] concat; 50.7 M variables."""
+    from oracle import yolo2_oracle as O2
+    specs = O2.conv_specs()
+    assert sum(s["k"] ** 2 * s["cin"] * s["cout"] + (5 if s["bn"] else 1) * s["cout"] for s in specs) == 50686397
+    x = np.arange(2 * 4 * 4 * 3, dtype=np.float32).reshape(2, 4, 4, 3)
+    r = O2.reorg(x)
+    assert r.shape == (2, 2, 2, 12)
+    np.testing.assert_array_equal(r[1, 1, 0], np.concatenate([x[1, 2, 0], x[1, 2, 1], x[1, 3, 0], x[1, 3, 1]]))
+    p = O2.pooling_layer(x)
+    np.testing.assert_array_equal(p[0, 1, 1], x[0, 2:, 2:].max(axis=(0, 1)))

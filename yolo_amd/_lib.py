@@ -32,6 +32,14 @@ SIGNATURES = {
     "yolo_upsample2x": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "yolo_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yolo_reorg_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "yolo2_net_create": (_i, [_i, _i, _i, _vp, _sz, _c.POINTER(_vp)]),
+    "yolo2_net_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "yolo2_conv_create": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_vp)]),
+    "yolo_maxpool2x2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "yolo_reorg2x": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "yolo2_decode": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "yolo2_nms_workspace_bytes": (_sz, [_i, _i, _i]),
+    "yolo2_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _c.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "yolo_nms_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "yolo_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -44,13 +44,15 @@ struct ConvLaunch {
     int out_ld, out_coff;
     int res_ld, res_coff;
     int kpad_bytes;        // bytes per packed weight row (multiple of 128)
-    int leaky;             // 1: 0.55x + 0.45|x| ; 0: linear
+    int leaky;             // 0: linear; 1: 0.55x + 0.45|x| (v3, model.py:8-12); 2: max(0.1x, x) (v2, yolo_v2.py:86)
     int upsample;          // 1: write every output pixel to the 2x2 block of a [B,2Ho,2Wo] tensor
     int out_f32;           // 1: out is float32 regardless of dtype (detection heads), scalar stores
+    int reorg;             // 1: space-to-depth scatter (yolo_v2.py:97-113): pixel (y,x) -> (y/2,x/2), channel block (y&1)*2+(x&1)
 };
 
 int launch_conv_igemm(int dtype, const ConvLaunch& p, hipStream_t stream);
 int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream);   // Cin = 3, 3x3 s1, f32 in
+int launch_maxpool2x2(int dtype, const void* in, int B, int H, int W, int C, void* out, hipStream_t stream);
 int launch_cast_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 int launch_cast_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t stream);
 

@@ -45,7 +45,7 @@ struct ConvK {
     int ksize, stride, pad;
     int in_ld, in_coff, out_ld, out_coff, res_ld, res_coff;
     int kpad_bytes, nsteps;
-    int leaky, upsample, out_f32;
+    int leaky, upsample, out_f32, reorg;
     int M, ntm, ntn;
 };
 
@@ -80,7 +80,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 float v = acc[i][j][r] + bv;
-                if (p.leaky) v = 0.55f * v + 0.45f * __builtin_fabsf(v);
+                if (p.leaky == 1) v = 0.55f * v + 0.45f * __builtin_fabsf(v);
+                else if (p.leaky == 2) v = __builtin_fmaxf(0.1f * v, v);
                 ct[row * LDC + col] = v;
             }
     }
@@ -121,7 +122,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
         const int row = idx / CH, ch = idx - row * CH;
-        const int m = m0 + row, n = n0 + ch * 8;
+        const int m = m0 + row;
+        int n = n0 + ch * 8;
         if (m >= p.M || n >= p.Cout) continue;
         f32x4 v0 = *(const f32x4*)(ct + row * LDC + ch * 8);
         f32x4 v1 = *(const f32x4*)(ct + row * LDC + ch * 8 + 4);
@@ -147,6 +149,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
             const long long base = ((long long)b * 2 * p.Ho + 2 * oy) * W2 + 2 * ox;
             pix[0] = base; pix[1] = base + 1; pix[2] = base + W2; pix[3] = base + W2 + 1;
             npix = 4;
+        } else if (p.reorg) {
+            const int b = m / HoWo;
+            const int r = m - b * HoWo;
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            pix[0] = ((long long)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+            n += ((oy & 1) * 2 + (ox & 1)) * p.Cout;
         } else {
             pix[0] = m;
         }
@@ -652,7 +660,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
     static const int forced = [] { const char* e = getenv("YOLO_CONV_CFG"); return e ? atoi(e) : -1; }();
     int cfg = forced;
     const int sz = BF16 ? 2 : 4;
-    const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32;
+    const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32 && !k.reorg;
     if (cfg >= 20 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
@@ -711,7 +719,8 @@ int launch_conv_igemm(int dtype, const ConvLaunch& p, hipStream_t stream) {
     k.in_ld = p.in_ld; k.in_coff = p.in_coff; k.out_ld = p.out_ld; k.out_coff = p.out_coff;
     k.res_ld = p.res_ld; k.res_coff = p.res_coff;
     k.kpad_bytes = p.kpad_bytes; k.nsteps = p.kpad_bytes / 128;
-    k.leaky = p.leaky; k.upsample = p.upsample; k.out_f32 = p.out_f32;
+    k.leaky = p.leaky; k.upsample = p.upsample; k.out_f32 = p.out_f32; k.reorg = p.reorg;
+    if (p.reorg) YOLO_REQUIRE(p.Ho % 2 == 0 && p.Wo % 2 == 0 && !p.upsample && !p.out_f32 && !p.res, YOLO_ERR_SHAPE, "conv: reorg needs even output size");
     const long long M = (long long)p.B * p.Ho * p.Wo;
     YOLO_REQUIRE(M > 0 && M < (1ll << 31) - 512, YOLO_ERR_SHAPE, "conv: M=%lld out of range", M);
     k.M = (int)M; k.ntm = k.ntn = 0;

@@ -32,6 +32,7 @@ static inline uint16_t f32_to_bf16_rne(float f) {
 // ---- one conv layer's device-resident parameters -------------------------------------------------
 struct ConvParams {
     int cin = 0, cout = 0, k = 0, stride = 1, bn = 1;
+    int act = 1;                // ConvLaunch::leaky mode applied when bn != 0
     int dtype = YOLO_DTYPE_F32;
     bool stem = false;          // Cin == 3 direct kernel, weights packed [27][Cout] f32
     int kpad_bytes = 0, npad = 0;
@@ -44,13 +45,14 @@ struct ConvParams {
 };
 
 // w_at(n, ci, ky, kx) abstracts the host layout (Darknet OIHW stream or TF HWIO variable).
-template <class WAt>
-static int pack_conv(ConvParams& L, WAt w_at, const float* p0, const float* p1, const float* p2, const float* p3) {
-    const int co = L.cout, ci = L.cin, k = L.k;
-    std::vector<float> scale(co), bias(co);
+// Fold inference BN into per-channel (scale, bias).  v3 (model.py:24-30, eps 1e-5):
+// y = (x - mean) * gamma / sqrt(var + eps) + beta.
+static void fold_bn(int co, int bn, const float* p0, const float* p1, const float* p2, const float* p3,
+                    std::vector<float>& scale, std::vector<float>& bias) {
+    scale.resize(co);
+    bias.resize(co);
     for (int n = 0; n < co; ++n) {
-        if (L.bn) {
-            // inference BN (model.py:24-30, eps 1e-5): y = (x - mean) * gamma / sqrt(var + eps) + beta
+        if (bn) {
             const float beta = p0[n], gamma = p1[n], mean = p2[n], var = p3[n];
             const float s = gamma / std::sqrt(var + 1e-5f);
             scale[n] = s;
@@ -60,6 +62,12 @@ static int pack_conv(ConvParams& L, WAt w_at, const float* p0, const float* p1, 
             bias[n] = p0[n];
         }
     }
+}
+
+// w_at(n, ci, ky, kx) abstracts the host layout (Darknet OIHW stream or TF HWIO variable).
+template <class WAt>
+static int pack_conv_sb(ConvParams& L, WAt w_at, const std::vector<float>& scale, const std::vector<float>& bias) {
+    const int co = L.cout, ci = L.cin, k = L.k;
     L.stem = (ci == 3);
     const int sz = L.dtype == YOLO_DTYPE_BF16 ? 2 : 4;
     size_t wbytes;
@@ -111,6 +119,13 @@ static int pack_conv(ConvParams& L, WAt w_at, const float* p0, const float* p1, 
     return YOLO_OK;
 }
 
+template <class WAt>
+static int pack_conv(ConvParams& L, WAt w_at, const float* p0, const float* p1, const float* p2, const float* p3) {
+    std::vector<float> scale, bias;
+    fold_bn(L.cout, L.bn, p0, p1, p2, p3, scale, bias);
+    return pack_conv_sb(L, w_at, scale, bias);
+}
+
 static int run_conv(const ConvParams& L, ConvLaunch p, hipStream_t stream) {
     p.w = L.w;
     p.bias = L.bias;
@@ -122,7 +137,7 @@ static int run_conv(const ConvParams& L, ConvLaunch p, hipStream_t stream) {
     p.kpad_bytes = L.kpad_bytes;
     p.Ho = (p.H + 2 * p.pad - L.k) / L.stride + 1;
     p.Wo = (p.W + 2 * p.pad - L.k) / L.stride + 1;
-    p.leaky = L.bn ? 1 : 0;         // model.py:32-36 vs :42-44
+    p.leaky = L.bn ? L.act : 0;     // model.py:32-36 vs :42-44 (v2: yolo_v2.py:86 vs :88)
     return L.stem ? launch_stem(L.dtype, p, stream) : launch_conv_igemm(L.dtype, p, stream);
 }
 
@@ -160,22 +175,115 @@ static std::vector<Spec> yolov3_specs(int class_num) {
 
 // One step of the static plan.  Tensor ids index Plan::tens; -1 = none, -2/-3/-4 = fm1/fm2/fm3, -5 = image.
 struct Step {
-    int layer;
+    int layer;                 // conv index, or -1 for a 2x2 max-pool step
     int in, out, res;
     int in_coff, out_coff;
     int upsample;
+    int reorg;
 };
 struct Tens { int h, w, ld; size_t bytes; int first, last; size_t offset; };
 struct Plan { std::vector<Step> steps; std::vector<Tens> tens; size_t ws_bytes = 0; };
 
 struct YoloNet {
-    int class_num = 0, dtype = 0;
+    int kind = 3;              // 3: YOLOv3 (model.py), 2: YOLOv2 (yolo_v2.py)
+    int class_num = 0, dtype = 0, box_per_cell = 5;
     std::vector<Spec> specs;
     std::vector<std::unique_ptr<ConvParams>> layers;
     std::map<std::tuple<int, int, int>, Plan> plans;
     std::mutex mu;
 };
 struct YoloConv { ConvParams p; };
+
+static void assign_offsets(Plan& P) {
+    // lifetimes -> offsets (first-fit over live intervals)
+    for (size_t s = 0; s < P.steps.size(); ++s) {
+        const Step& st = P.steps[s];
+        for (int id : {st.in, st.out, st.res})
+            if (id >= 0) {
+                if (P.tens[id].first < 0) P.tens[id].first = (int)s;
+                P.tens[id].last = (int)s;
+            }
+    }
+    std::vector<int> placed;
+    for (size_t s = 0; s < P.steps.size(); ++s)
+        for (size_t id = 0; id < P.tens.size(); ++id) {
+            Tens& t = P.tens[id];
+            if (t.first != (int)s) continue;
+            // concat buffers are created early (first written mid-backbone); plain first-fit
+            size_t off = 0;
+            bool moved = true;
+            while (moved) {
+                moved = false;
+                for (int o : placed) {
+                    const Tens& u = P.tens[o];
+                    if (u.last < t.first || u.first > t.last) continue;          // disjoint lifetimes
+                    if (off < u.offset + u.bytes && u.offset < off + t.bytes) { off = u.offset + u.bytes; moved = true; }
+                }
+            }
+            t.offset = off;
+            placed.push_back((int)id);
+            if (off + t.bytes > P.ws_bytes) P.ws_bytes = off + t.bytes;
+        }
+}
+
+// yolo_v2.build_networks (reference yolo_v2/yolo/yolo_v2.py:32-70): 23 convs, 5 max-pools, the passthrough
+// 1x1 conv scattered space-to-depth into channels [0:256) of the concat buffer whose channels [256:1280)
+// are written by 24_conv.
+static std::vector<Spec> yolov2_specs(int num_class, int box_per_cell) {
+    std::vector<Spec> v;
+    const int s[22][3] = {{3, 3, 32}, {3, 32, 64}, {3, 64, 128}, {1, 128, 64}, {3, 64, 128}, {3, 128, 256}, {1, 256, 128},
+                          {3, 128, 256}, {3, 256, 512}, {1, 512, 256}, {3, 256, 512}, {1, 512, 256}, {3, 256, 512},
+                          {3, 512, 1024}, {1, 1024, 512}, {3, 512, 1024}, {1, 1024, 512}, {3, 512, 1024}, {3, 1024, 1024},
+                          {3, 1024, 1024}, {1, 512, 64}, {3, 1280, 1024}};
+    for (auto& e : s) v.push_back({e[1], e[2], e[0], 1, 1});
+    v.push_back({1024, box_per_cell * (num_class + 5), 1, 1, 0});
+    return v;
+}
+
+static Plan build_plan_v2(const YoloNet& net, int B, int H, int W) {
+    Plan P;
+    const int sz = net.dtype == YOLO_DTYPE_BF16 ? 2 : 4;
+    auto tensor = [&](int h, int w, int ld) {
+        P.tens.push_back({h, w, ld, align_up((size_t)B * h * w * ld * sz, 256), -1, -1, 0});
+        return (int)P.tens.size() - 1;
+    };
+    int li = 0, h = H, w = W;
+    auto conv = [&](int in, int out = -1, int out_coff = 0, int reorg = 0) {
+        const Spec& s = net.specs[li];
+        if (out == -1) out = tensor(h, w, s.cout);
+        P.steps.push_back({li, in, out, -1, 0, out_coff, 0, reorg});
+        ++li;
+        return out;
+    };
+    auto pool = [&](int in) {
+        const int c = P.tens[in].ld;
+        h /= 2; w /= 2;
+        const int out = tensor(h, w, c);
+        P.steps.push_back({-1, in, out, -1, 0, 0, 0, 0});
+        return out;
+    };
+    int x = pool(conv(-5));                      // 0_conv, 1_pool
+    x = pool(conv(x));                           // 2_conv, 3_pool
+    x = conv(conv(conv(x)));                     // 4..6
+    x = pool(x);                                 // 7_pool
+    x = conv(conv(conv(x)));                     // 8..10
+    x = pool(x);                                 // 11_pool
+    x = conv(conv(conv(conv(x))));               // 12..15
+    const int net16 = conv(x);                   // 16_conv
+    const int h16 = h, w16 = w;
+    x = pool(net16);                             // 17_pool
+    for (int i = 0; i < 6; ++i) x = conv(x);     // 18..23
+    const int cat = tensor(h, w, 256 + 1024);    // [reorg(26_conv) | net24]   yolo_v2.py:64-65
+    conv(x, cat, 256);                           // 24_conv -> channels [256:1280)
+    const int hs = h, ws = w;
+    h = h16; w = w16;
+    conv(net16, cat, 0, 1);                      // 26_conv + reorg -> channels [0:256)
+    h = hs; w = ws;
+    x = conv(cat);                               // 29_conv
+    conv(x, -2);                                 // 30_conv -> logits (f32, bias only)
+    assign_offsets(P);
+    return P;
+}
 
 static Plan build_plan(const YoloNet& net, int B, int H, int W) {
     Plan P;
@@ -190,7 +298,7 @@ static Plan build_plan(const YoloNet& net, int B, int H, int W) {
         const Spec& s = net.specs[li];
         const int ho = h_in / s.stride, wo = w_in / s.stride;
         if (out == -1) out = tensor(ups ? 2 * ho : ho, ups ? 2 * wo : wo, s.cout);
-        P.steps.push_back({li, in, out, res, in_coff, out_coff, ups});
+        P.steps.push_back({li, in, out, res, in_coff, out_coff, ups, 0});
         ++li;
         return out;
     };
@@ -236,37 +344,7 @@ static Plan build_plan(const YoloNet& net, int B, int H, int W) {
     h = g3h; w = g3w;
     int net3 = yolo_block(concat2, dummy);
     conv(net3, 0, h, w, -1, -4);                             // feature_map_3
-    // lifetimes -> offsets (first-fit over live intervals)
-    for (size_t s = 0; s < P.steps.size(); ++s) {
-        const Step& st = P.steps[s];
-        for (int id : {st.in, st.out, st.res})
-            if (id >= 0) {
-                if (P.tens[id].first < 0) P.tens[id].first = (int)s;
-                P.tens[id].last = (int)s;
-            }
-    }
-    std::vector<int> order(P.tens.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::vector<int> placed;
-    for (size_t s = 0; s < P.steps.size(); ++s)
-        for (size_t id = 0; id < P.tens.size(); ++id) {
-            Tens& t = P.tens[id];
-            if (t.first != (int)s) continue;
-            // concat buffers are created early (first written mid-backbone); plain first-fit
-            size_t off = 0;
-            bool moved = true;
-            while (moved) {
-                moved = false;
-                for (int o : placed) {
-                    const Tens& u = P.tens[o];
-                    if (u.last < t.first || u.first > t.last) continue;          // disjoint lifetimes
-                    if (off < u.offset + u.bytes && u.offset < off + t.bytes) { off = u.offset + u.bytes; moved = true; }
-                }
-            }
-            t.offset = off;
-            placed.push_back((int)id);
-            if (off + t.bytes > P.ws_bytes) P.ws_bytes = off + t.bytes;
-        }
+    assign_offsets(P);
     return P;
 }
 
@@ -276,7 +354,8 @@ static int get_plan(YoloNet* net, int B, int H, int W, const Plan** out) {
     std::lock_guard<std::mutex> g(net->mu);
     auto key = std::make_tuple(B, H, W);
     auto it = net->plans.find(key);
-    if (it == net->plans.end()) it = net->plans.emplace(key, build_plan(*net, B, H, W)).first;
+    if (it == net->plans.end())
+        it = net->plans.emplace(key, net->kind == 2 ? build_plan_v2(*net, B, H, W) : build_plan(*net, B, H, W)).first;
     *out = &it->second;
     return YOLO_OK;
 }
@@ -314,6 +393,61 @@ extern "C" int yolo_net_create(int class_num, int dtype, const float* stream, si
     return YOLO_OK;
 }
 
+static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                        float* fm1, float* fm2, float* fm3, void* stream, hipEvent_t* events);
+
+// YOLOv2 weights: the reference keeps them in a TF checkpoint; this entry takes the variables concatenated in
+// creation order per conv (yolo_v2.py:75-83): weight [k,k,cin,cout] (HWIO), biases, then for batch-norm layers
+// scale, shift, rolling_mean, rolling_variance.  Fold: y = scale*(x-mean)/sqrt(var+1e-5) + shift + biases.
+extern "C" int yolo2_net_create(int num_class, int box_per_cell, int dtype, const float* vars, size_t n_floats, YoloNet** out) {
+    YOLO_REQUIRE(vars && out, YOLO_ERR_ARG, "yolo2_net_create: null pointer");
+    YOLO_REQUIRE(num_class > 0 && num_class <= 4096 && box_per_cell > 0 && box_per_cell <= 16, YOLO_ERR_ARG, "yolo2_net_create: bad sizes");
+    YOLO_REQUIRE(dtype == YOLO_DTYPE_F32 || dtype == YOLO_DTYPE_BF16, YOLO_ERR_ARG, "yolo2_net_create: dtype %d", dtype);
+    std::unique_ptr<YoloNet> net(new YoloNet);
+    net->kind = 2;
+    net->class_num = num_class;
+    net->box_per_cell = box_per_cell;
+    net->dtype = dtype;
+    net->specs = yolov2_specs(num_class, box_per_cell);
+    size_t need = 0;
+    for (const Spec& s : net->specs) need += (size_t)s.k * s.k * s.cin * s.cout + (size_t)(s.bn ? 5 : 1) * s.cout;
+    YOLO_REQUIRE(need == n_floats, YOLO_ERR_SHAPE, "yolo2_net_create: %zu floats given, architecture needs %zu", n_floats, need);
+    const float* ptr = vars;
+    for (const Spec& s : net->specs) {
+        std::unique_ptr<ConvParams> L(new ConvParams);
+        L->cin = s.cin; L->cout = s.cout; L->k = s.k; L->stride = 1; L->bn = s.bn; L->dtype = dtype; L->act = 2;
+        const float* wk = ptr;
+        ptr += (size_t)s.k * s.k * s.cin * s.cout;
+        const float* biases = ptr;
+        ptr += s.cout;
+        std::vector<float> scale(s.cout), bias(s.cout);
+        if (s.bn) {
+            const float *sc = ptr, *sh = ptr + s.cout, *mean = ptr + 2 * (size_t)s.cout, *var = ptr + 3 * (size_t)s.cout;
+            ptr += 4 * (size_t)s.cout;
+            for (int n = 0; n < s.cout; ++n) {
+                const float f = sc[n] / std::sqrt(var[n] + 1e-5f);       // yolo_v2.py:84
+                scale[n] = f;
+                bias[n] = sh[n] - mean[n] * f + biases[n];               // yolo_v2.py:85
+            }
+        } else {
+            for (int n = 0; n < s.cout; ++n) { scale[n] = 1.0f; bias[n] = biases[n]; }   // yolo_v2.py:88
+        }
+        const int ci = s.cin, co = s.cout, k = s.k;
+        int rc = pack_conv_sb(*L, [=](int n, int c, int ky, int kx) { return wk[(((size_t)ky * k + kx) * ci + c) * co + n]; }, scale, bias);
+        if (rc != YOLO_OK) return rc;
+        net->layers.push_back(std::move(L));
+    }
+    *out = net.release();
+    return YOLO_OK;
+}
+
+// images [B,H,W,3] f32 in [-1,1] -> logits [B,H/32,W/32,box_per_cell*(5+num_class)] f32 (yolo_v2.py:32-70).
+extern "C" int yolo2_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
+                                 size_t workspace_bytes, float* logits, void* stream) {
+    YOLO_REQUIRE(net && net->kind == 2, YOLO_ERR_ARG, "yolo2_net_forward: not a YOLOv2 handle");
+    return forward_impl(net, images, B, H, W, workspace, workspace_bytes, logits, nullptr, nullptr, stream, nullptr);
+}
+
 extern "C" int yolo_net_destroy(YoloNet* net) {
     delete net;
     return YOLO_OK;
@@ -330,17 +464,24 @@ extern "C" size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int
 
 static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
                         float* fm1, float* fm2, float* fm3, void* stream, hipEvent_t* events) {
-    YOLO_REQUIRE(net && images && workspace && fm1 && fm2 && fm3, YOLO_ERR_ARG, "forward: null pointer");
+    YOLO_REQUIRE(net && images && workspace && fm1 && (net->kind == 2 || (fm2 && fm3)), YOLO_ERR_ARG, "forward: null pointer");
     const Plan* P = nullptr;
     int rc = get_plan(net, B, H, W, &P);
     if (rc != YOLO_OK) return rc;
     YOLO_REQUIRE(workspace_bytes >= P->ws_bytes, YOLO_ERR_WORKSPACE, "forward: workspace %zu < %zu bytes", workspace_bytes, P->ws_bytes);
     YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "forward: workspace must be 256-byte aligned");
-    const int nout = 3 * (5 + net->class_num);
+    const int nout = (net->kind == 2 ? net->box_per_cell : 3) * (5 + net->class_num);
     float* fms[3] = {fm1, fm2, fm3};
     int h_in = H, w_in = W;
     (void)h_in; (void)w_in;
     for (const Step& st : P->steps) {
+        if (st.layer < 0) {                       // pooling_layer (yolo_v2.py:91-94)
+            const Tens& ti = P->tens[st.in];
+            const Tens& to = P->tens[st.out];
+            rc = launch_maxpool2x2(net->dtype, (char*)workspace + ti.offset, B, ti.h, ti.w, ti.ld, (char*)workspace + to.offset, (hipStream_t)stream);
+            if (rc != YOLO_OK) return rc;
+            continue;
+        }
         const ConvParams& L = *net->layers[st.layer];
         ConvLaunch p;
         memset(&p, 0, sizeof(p));
@@ -360,6 +501,7 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
             p.res = (char*)workspace + t.offset; p.res_ld = t.ld; p.res_coff = 0;
         }
         p.upsample = st.upsample;
+        p.reorg = st.reorg;
         if (events) YOLO_HIP_CHECK(hipEventRecord(events[st.layer], (hipStream_t)stream));
         rc = run_conv(L, p, (hipStream_t)stream);
         if (rc != YOLO_OK) return rc;
@@ -370,6 +512,7 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
 
 extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
                                 float* fm1, float* fm2, float* fm3, void* stream) {
+    YOLO_REQUIRE(net && net->kind == 3, YOLO_ERR_ARG, "yolo_net_forward: not a YOLOv3 handle");
     return forward_impl(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream, nullptr);
 }
 
@@ -378,7 +521,7 @@ extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H,
 extern "C" int yolo_net_forward_timed(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
                                       size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream,
                                       float* layer_ms, int n_layers) {
-    YOLO_REQUIRE(net && layer_ms, YOLO_ERR_ARG, "forward_timed: null pointer");
+    YOLO_REQUIRE(net && layer_ms && net->kind == 3, YOLO_ERR_ARG, "forward_timed: needs a YOLOv3 handle and layer_ms");
     const int nl = (int)net->layers.size();
     YOLO_REQUIRE(n_layers == nl, YOLO_ERR_ARG, "forward_timed: layer_ms must hold %d floats", nl);
     std::vector<hipEvent_t> ev(nl + 1);
@@ -421,6 +564,41 @@ extern "C" int yolo_conv_create(int dtype, int cin, int cout, int ksize, int str
     L.cin = cin; L.cout = cout; L.k = ksize; L.stride = stride; L.bn = bn; L.dtype = dtype;
     int rc = pack_conv(L, [=](int n, int ci, int ky, int kx) { return w_hwio[(((size_t)ky * ksize + kx) * cin + ci) * cout + n]; },
                        p0, p1, p2, p3);
+    if (rc != YOLO_OK) return rc;
+    *out = c.release();
+    return YOLO_OK;
+}
+
+// conv_layer of YOLOv2 (reference yolo_v2/yolo/yolo_v2.py:73-89) as a single layer: SAME conv (no bias) ->
+// batch_normalization(mean, variance, shift, scale, 1e-5) -> + biases -> max(0.1x, x); batch_norm == 0: conv + biases.
+extern "C" int yolo2_conv_create(int dtype, int cin, int cout, int ksize, int batch_norm, const float* weight_hwio,
+                                 const float* biases, const float* scale, const float* shift, const float* mean,
+                                 const float* variance, YoloConv** out) {
+    YOLO_REQUIRE(weight_hwio && biases && out, YOLO_ERR_ARG, "conv2_create: null pointer");
+    YOLO_REQUIRE(!batch_norm || (scale && shift && mean && variance), YOLO_ERR_ARG, "conv2_create: batch_norm needs scale, shift, mean, variance");
+    YOLO_REQUIRE(dtype == YOLO_DTYPE_F32 || dtype == YOLO_DTYPE_BF16, YOLO_ERR_ARG, "conv2_create: dtype %d", dtype);
+    YOLO_REQUIRE((ksize == 1 || ksize == 3) && cin > 0 && cout > 0, YOLO_ERR_UNSUPPORTED, "conv2_create: ksize %d", ksize);
+    const int sz = dtype == YOLO_DTYPE_BF16 ? 2 : 4;
+    if (cin == 3)
+        YOLO_REQUIRE(ksize == 3 && cout == 32, YOLO_ERR_UNSUPPORTED, "conv2_create: Cin=3 only as the 3x3 3->32 stem");
+    else
+        YOLO_REQUIRE((cin * sz) % 64 == 0 && (128 % (cin * sz) == 0 || (cin * sz) % 128 == 0), YOLO_ERR_SHAPE,
+                     "conv2_create: Cin=%d unsupported (need Cin*sizeof a divisor or multiple of 128 bytes)", cin);
+    std::unique_ptr<YoloConv> c(new YoloConv);
+    ConvParams& L = c->p;
+    L.cin = cin; L.cout = cout; L.k = ksize; L.stride = 1; L.bn = batch_norm; L.dtype = dtype; L.act = 2;
+    std::vector<float> sc(cout), bi(cout);
+    for (int n = 0; n < cout; ++n) {
+        if (batch_norm) {
+            const float f = scale[n] / std::sqrt(variance[n] + 1e-5f);   // yolo_v2.py:84
+            sc[n] = f;
+            bi[n] = shift[n] - mean[n] * f + biases[n];                  // yolo_v2.py:85
+        } else {
+            sc[n] = 1.0f;
+            bi[n] = biases[n];                                           // yolo_v2.py:88
+        }
+    }
+    int rc = pack_conv_sb(L, [=](int n, int ci, int ky, int kx) { return weight_hwio[(((size_t)ky * ksize + kx) * cin + ci) * cout + n]; }, sc, bi);
     if (rc != YOLO_OK) return rc;
     *out = c.release();
     return YOLO_OK;

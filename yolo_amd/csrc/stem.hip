@@ -43,9 +43,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
             }
         }
     }
-    if (leaky) {
+    if (leaky == 1) {
 #pragma unroll
         for (int n = 0; n < COUT; ++n) acc[n] = 0.55f * acc[n] + 0.45f * __builtin_fabsf(acc[n]);
+    } else if (leaky == 2) {
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = __builtin_fmaxf(0.1f * acc[n], acc[n]);
     }
     if constexpr (BF16) {
         char* op = out + (m * out_ld + out_coff) * 2;
@@ -124,7 +127,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
             float v = acc[r] + bv;
-            if (leaky) v = 0.55f * v + 0.45f * __builtin_fabsf(v);
+            if (leaky == 1) v = 0.55f * v + 0.45f * __builtin_fabsf(v);
+            else if (leaky == 2) v = __builtin_fmaxf(0.1f * v, v);
             tl[row * 33 + fr] = v;
         }
         const int pr = lane >> 1, c0 = (lane & 1) * 16;
@@ -158,6 +162,61 @@ int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream) {
     } else
         hipLaunchKernelGGL((stem_kernel<false, 32>), dim3(grid), dim3(256), 0, stream, (const float*)p.in,
                            (const float*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+static unsigned cast_grid_fwd(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+// ---- pooling_layer (reference yolo_v2/yolo/yolo_v2.py:91-94): max_pool 2x2 stride 2 SAME on even sizes.
+// HBM-bound: 16 bytes per lane, channel-contiguous.
+template <bool BF16>
+__global__ void maxpool2x2_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int B, int H, int W, int C16) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t total = (size_t)B * Ho * Wo * C16;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C16);
+        size_t t = i / C16;
+        const int x = (int)(t % Wo);
+        t /= Wo;
+        const int y = (int)(t % Ho);
+        const size_t b = t / Ho;
+        const size_t base = ((b * H + 2 * y) * W + 2 * x) * C16 + c;
+        const u32x4 q[4] = {in[base], in[base + C16], in[base + (size_t)W * C16], in[base + (size_t)W * C16 + C16]};
+        u32x4 o;
+        if constexpr (BF16) {
+            bf16x8 r = __builtin_bit_cast(bf16x8, q[0]);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const bf16x8 v = __builtin_bit_cast(bf16x8, q[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = (float)v[e] > (float)r[e] ? v[e] : r[e];
+            }
+            o = __builtin_bit_cast(u32x4, r);
+        } else {
+            f32x4 r = __builtin_bit_cast(f32x4, q[0]);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const f32x4 v = __builtin_bit_cast(f32x4, q[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = v[e] > r[e] ? v[e] : r[e];
+            }
+            o = __builtin_bit_cast(u32x4, r);
+        }
+        out[i] = o;
+    }
+}
+
+int launch_maxpool2x2(int dtype, const void* in, int B, int H, int W, int C, void* out, hipStream_t stream) {
+    const int per16 = dtype == YOLO_DTYPE_BF16 ? 8 : 4;
+    YOLO_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % per16 == 0, YOLO_ERR_SHAPE,
+                 "maxpool2x2: need even H, W and C %% %d == 0", per16);
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / per16);
+    if (dtype == YOLO_DTYPE_BF16)
+        hipLaunchKernelGGL(maxpool2x2_kernel<true>, dim3(cast_grid_fwd(total)), dim3(256), 0, stream, (const u32x4*)in, (u32x4*)out, B, H, W, C / per16);
+    else
+        hipLaunchKernelGGL(maxpool2x2_kernel<false>, dim3(cast_grid_fwd(total)), dim3(256), 0, stream, (const u32x4*)in, (u32x4*)out, B, H, W, C / per16);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
 }
@@ -227,4 +286,37 @@ extern "C" int yolo_upsample2x(const float* in, int B, int H, int W, int C, floa
                        (const yolo::f32x4*)in, (yolo::f32x4*)out, B, H, W, C / 4);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
+}
+
+// ---- reorg (reference yolo_v2/yolo/yolo_v2.py:97-113): space-to-depth 2x2, channel block (dy*2+dx)*C.
+// The fused network never runs this (26_conv scatters in its epilogue); layer-level drop-in only.
+__global__ void reorg2x_kernel(const yolo::f32x4* __restrict__ in, yolo::f32x4* __restrict__ out, int B, int H, int W, int C4) {
+    const size_t total = (size_t)B * H * W * C4;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const size_t b = t / H;
+        out[(((b * Ho + (y >> 1)) * Wo + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * C4 + c] = in[i];
+    }
+}
+
+extern "C" int yolo_reorg2x(const float* in, int B, int H, int W, int C, float* out, void* stream) {
+    YOLO_REQUIRE(in && out, YOLO_ERR_ARG, "reorg2x: null pointer");
+    YOLO_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, YOLO_ERR_SHAPE, "reorg2x: need even H, W and C %% 4 == 0");
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(reorg2x_kernel, dim3(yolo::cast_grid_fwd(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const yolo::f32x4*)in, (yolo::f32x4*)out, B, H, W, C / 4);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+extern "C" int yolo_maxpool2x2(const float* in, int B, int H, int W, int C, float* out, void* stream) {
+    YOLO_REQUIRE(in && out, YOLO_ERR_ARG, "maxpool2x2: null pointer");
+    return yolo::launch_maxpool2x2(YOLO_DTYPE_F32, in, B, H, W, C, out, (hipStream_t)stream);
 }
