@@ -22,6 +22,10 @@ sys.path.insert(0, ROOT)
 
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 F32_PEAK_TFLOPS = 157.3
+# HBM-side bytes per launch of a kernel instantiation, from the committed PMC passes (profiles/, see DESIGN.md
+# section 5): 2 x FETCH_SIZE + WRITE_SIZE averaged over the launches of one bench step (FETCH_SIZE doubled as
+# MI355X_MICROARCH.md "HBM" prescribes for gfx950).  Keyed by (kernel, batch, size); None when not measured.
+TRAFFIC_BYTES_PER_LAUNCH = {}
 
 
 def conv_flops_per_image(info, H, W):
@@ -126,32 +130,44 @@ def main():
         dt = float(t.item())
     ndet = int(out[4].sum().item())
 
-    # ---- roofline of the dominant kernel (conv_igemm 128x128 tile), HIP events on the launch stream ----
+    # ---- roofline of the dominant kernel: per-layer HIP events recorded by the library on the launch stream
+    # (yolo_net_forward_timed), layers grouped by the kernel INSTANTIATION the library launched for them ----
     reps = 5
     acc = None
     for _ in range(reps):
         _, ms, info = net.forward_timed(images)
         acc = ms.astype(np.float64) if acc is None else acc + ms
     layer_ms = acc / reps
+    kernels = net.layer_kernels
     flops = conv_flops_per_image(info, S, S)
-    dom = [i for i, (cin, cout, k, s) in enumerate(info) if cin != 3 and cout > 64]     # 128x128-tile launches
-    dom_flops = sum(flops[i] for i in dom) * B
-    dom_ms = float(sum(layer_ms[i] for i in dom))
+    groups = {}
+    for i, name in enumerate(kernels):
+        g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        g["launches"] += 1
+        g["ms"] += float(layer_ms[i])
+        g["flops"] += flops[i] * B
+    dom_name = max(groups, key=lambda n: groups[n]["ms"])
+    dom = groups[dom_name]
     peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
-    achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s,128,128,2,2>" % ("bf16" if args.dtype == "bf16" else "f32"),
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((dom_name, B, S))
+    roofline = {"bound": "mfma", "kernel": dom_name,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None, "launches_per_step": len(dom),
-                "avg_launch_ms": round(dom_ms / len(dom), 5),
-                "flops_per_launch_avg": dom_flops / len(dom),
+                "traffic": traffic, "launches_per_step": dom["launches"],
+                "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
+                "flops_per_launch_avg": dom["flops"] / dom["launches"],
+                "share_of_conv_stack_ms": round(dom["ms"] / float(layer_ms.sum()), 3),
                 "conv_stack_ms": round(float(layer_ms.sum()), 4),
-                "conv_stack_tflops": round(sum(flops) * B / (float(layer_ms.sum()) * 1e-3) / 1e12, 2)}
+                "conv_stack_tflops": round(sum(flops) * B / (float(layer_ms.sum()) * 1e-3) / 1e12, 2),
+                "kernels": [{"kernel": n, "launches": g["launches"], "ms": round(g["ms"], 4),
+                             "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 1)}
+                            for n, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]}
     if args.layer_table and rank == 0:
         with open(args.layer_table, "w") as f:
             f.write("# layer cin cout k stride ms GFLOP TFLOP/s   (batch %d, %dx%d, %s)\n" % (B, S, S, args.dtype))
             for i, ((cin, cout, k, s), ms_i) in enumerate(zip(info, layer_ms)):
-                f.write("%2d %4d %4d %d %d %8.4f %9.3f %8.2f\n" % (i, cin, cout, k, s, ms_i, flops[i] * B / 1e9,
-                                                                   flops[i] * B / (ms_i * 1e-3) / 1e12))
+                f.write("%2d %4d %4d %d %d %8.4f %9.3f %8.2f  %s\n" % (i, cin, cout, k, s, ms_i, flops[i] * B / 1e9,
+                                                                       flops[i] * B / (ms_i * 1e-3) / 1e12, kernels[i]))
 
     if rank == 0:
         res = {

@@ -65,6 +65,10 @@ int yolo_net_forward_timed(YoloNet* net, const float* images, int B, int H, int 
                            size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream,
                            float* layer_ms, int n_layers);
 
+/* Measurement aid (no counterpart in the reference): name of the kernel instantiation the last
+ * yolo_net_forward_timed launched for `layer`, spelled as rocprofv3 prints it (no return type / arguments). */
+const char* yolo_net_layer_kernel(const YoloNet* net, int layer);
+
 /* ---- one conv layer: replaces conv2d (yolo_v3/utils/layer_utils.py:9-21) under the arg_scope of
  * yolo_v3/model.py:32-36 (conv no-bias + BN(eps 1e-5, inference) + leaky 0.1), or, with bn == 0,
  * the detection conv of model.py:42-44 (conv + bias, no activation).

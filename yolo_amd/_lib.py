@@ -23,6 +23,7 @@ SIGNATURES = {
     "yolo_net_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "yolo_net_num_layers": (_i, [_vp]),
     "yolo_net_layer_info": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "yolo_net_layer_kernel": (_c.c_char_p, [_vp, _i]),
     "yolo_net_forward_timed": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i]),
     "yolo_conv_create": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_vp)]),
     "yolo_conv_destroy": (_i, [_vp]),

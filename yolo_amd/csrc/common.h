@@ -50,6 +50,13 @@ struct ConvLaunch {
     int reorg;             // 1: space-to-depth scatter (yolo_v2.py:97-113): pixel (y,x) -> (y/2,x/2), channel block (y&1)*2+(x&1)
 };
 
+// Measurement aid: when `record_kernel_names` is set (only yolo_net_forward_timed sets it), every launcher
+// writes the name of the kernel instantiation it launches (as rocprofv3 prints it, without return type and
+// arguments) with note_kernel(); last_kernel_name() returns it.
+extern thread_local bool record_kernel_names;
+void note_kernel(const char* fmt, ...);
+const char* last_kernel_name();
+
 int launch_conv_igemm(int dtype, const ConvLaunch& p, hipStream_t stream);
 int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream);   // Cin = 3, 3x3 s1, f32 in
 int launch_maxpool2x2(int dtype, const void* in, int B, int H, int W, int C, void* out, hipStream_t stream);

@@ -627,6 +627,7 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
+    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N);
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
@@ -649,6 +650,7 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
+    note_kernel("yolo::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, STAGES);
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;

@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 #include <tuple>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -14,6 +15,17 @@
 namespace yolo {
 
 static thread_local char g_err[512] = "";
+
+thread_local bool record_kernel_names = false;
+static thread_local char g_kernel_name[128] = "";
+void note_kernel(const char* fmt, ...) {
+    if (!record_kernel_names) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel_name, sizeof(g_kernel_name), fmt, ap);
+    va_end(ap);
+}
+const char* last_kernel_name() { return g_kernel_name; }
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -187,6 +199,7 @@ struct Plan { std::vector<Step> steps; std::vector<Tens> tens; size_t ws_bytes =
 struct YoloNet {
     int kind = 3;              // 3: YOLOv3 (model.py), 2: YOLOv2 (yolo_v2.py)
     int class_num = 0, dtype = 0, box_per_cell = 5;
+    std::vector<std::string> kernel_names;   // per layer, filled by yolo_net_forward_timed
     std::vector<Spec> specs;
     std::vector<std::unique_ptr<ConvParams>> layers;
     std::map<std::tuple<int, int, int>, Plan> plans;
@@ -505,6 +518,7 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
         if (events) YOLO_HIP_CHECK(hipEventRecord(events[st.layer], (hipStream_t)stream));
         rc = run_conv(L, p, (hipStream_t)stream);
         if (rc != YOLO_OK) return rc;
+        if (record_kernel_names) net->kernel_names[st.layer] = last_kernel_name();
     }
     if (events) YOLO_HIP_CHECK(hipEventRecord(events[P->steps.size()], (hipStream_t)stream));
     return YOLO_OK;
@@ -526,7 +540,10 @@ extern "C" int yolo_net_forward_timed(YoloNet* net, const float* images, int B, 
     YOLO_REQUIRE(n_layers == nl, YOLO_ERR_ARG, "forward_timed: layer_ms must hold %d floats", nl);
     std::vector<hipEvent_t> ev(nl + 1);
     for (auto& e : ev) YOLO_HIP_CHECK(hipEventCreate(&e));
+    net->kernel_names.assign(nl, std::string());
+    record_kernel_names = true;
     int rc = forward_impl(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream, ev.data());
+    record_kernel_names = false;
     if (rc == YOLO_OK) {
         hipError_t e = hipStreamSynchronize((hipStream_t)stream);
         if (e != hipSuccess) { set_error("forward_timed: sync failed: %s", hipGetErrorString(e)); rc = YOLO_ERR_HIP; }
@@ -543,6 +560,13 @@ extern "C" int yolo_net_layer_info(const YoloNet* net, int layer, int* cin, int*
     const Spec& s = net->specs[layer];
     *cin = s.cin; *cout = s.cout; *ksize = s.k; *stride = s.stride;
     return YOLO_OK;
+}
+
+// Name of the kernel instantiation the last yolo_net_forward_timed launched for `layer` (as rocprofv3 prints
+// it, without return type and argument list); "" before the first timed forward.
+extern "C" const char* yolo_net_layer_kernel(const YoloNet* net, int layer) {
+    if (!net || layer < 0 || layer >= (int)net->kernel_names.size()) return "";
+    return net->kernel_names[layer].c_str();
 }
 
 // ---- single layer ---------------------------------------------------------------------------------

@@ -157,11 +157,14 @@ int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream) {
         const long long ngroups = (npix + 31) / 32;
         long long g = (ngroups + 3) / 4;
         if (g > 256 * 16) g = 256 * 16;
+        note_kernel("yolo::stem_mfma_kernel");
         hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.in,
                            (const u32x4*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
-    } else
+    } else {
+        note_kernel("yolo::stem_kernel<false, 32>");
         hipLaunchKernelGGL((stem_kernel<false, 32>), dim3(grid), dim3(256), 0, stream, (const float*)p.in,
                            (const float*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
+    }
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
 }

@@ -79,7 +79,8 @@ class yolov3(object):
         return fms[0], fms[1], fms[2]
 
     def forward_timed(self, inputs):
-        """Measurement aid: forward with per-layer hipEvent timing -> (fms, ms[75], [(cin,cout,k,stride)])."""
+        """Measurement aid: forward with per-layer hipEvent timing -> (fms, ms[75], [(cin,cout,k,stride)]);
+        `self.layer_kernels` then holds the kernel instantiation launched for every layer."""
         x = _tensor.as_dev_f32(inputs)
         B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
         self.img_size = (H, W)
@@ -99,6 +100,7 @@ class yolov3(object):
             v = [ctypes.c_int() for _ in range(4)]
             _lib.check(L.yolo_net_layer_info(self._net, i, *[ctypes.byref(t) for t in v]))
             info.append(tuple(t.value for t in v))
+        self.layer_kernels = [L.yolo_net_layer_kernel(self._net, i).decode() for i in range(nl)]
         return fms, ms, info
 
     def detect(self, inputs, max_boxes=30, score_thresh=0.4, iou_thresh=0.5):
