@@ -1,0 +1,282 @@
+// Fused front of Darknet-53 (bf16 path): conv 3->32 3x3 s1 + BN + leaky (the stem) followed by conv 32->64 3x3 s2
+// + BN + leaky, the first two conv2d calls of darknet53_body (reference yolo_v3/utils/layer_utils.py:31-32; the
+// stride-2 conv pads 1/1 explicitly, :11-20).  As two kernels this pair moves 133 MB (image) + 709 MB (stem output,
+// written) + 709 MB (read again) + 354 MB at batch 64 and is bound by HBM; fused, the 416x416x32 stem output never
+// leaves the CU: 133 MB in, 354 MB out.
+//
+// One workgroup of 64*TH threads walks over output tiles of TH x 16 pixels (of the H/2 x W/2 map):
+//   1. image patch (2TH+3) x 35 x 3 f32 -> LDS (zero outside the image = the stem's SAME padding); the loads of the
+//      NEXT tile's patch are issued before the compute phases and written to LDS after them.
+//   2. stem on MFMA for the (2TH+1) x 33 stem pixels the tile needs (K = 27 padded to 32, two
+//      v_mfma_f32_32x32x16_bf16 per 32 pixels, weights as the A operand so that a lane ends up with 4 x 4
+//      consecutive channels of ONE pixel), bias + leaky, zero where the stem pixel lies outside the image (the
+//      stride-2 conv's explicit padding), bf16 -> LDS stem patch.
+//      Stem patch layout [channel chunk of 8][x parity][y][x / 2][16 B]: the stride-2 conv reads pixels 2 apart in x,
+//      which are 16 B apart here, so every fragment read is a conflict-free ds_read_b128.
+//   3. stride-2 conv as an implicit GEMM out of LDS: per wave 32 pixels x 32 channels, 18 k-slices (9 taps x 2 channel
+//      halves); weights [64][288] bf16 staged once per workgroup (row stride 592 B: conflict-free fragment reads).
+//   4. bias + leaky -> bf16 -> LDS staging -> 16-byte stores, 128 contiguous bytes per pixel.
+#include "common.h"
+
+namespace yolo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <int TH>
+constexpr int front_lds_bytes() { return (2 * TH + 3) * 108 * 4 + 8 * (2 * TH + 1) * 17 * 16 + 64 * 592 + TH * 16 * 144; }
+
+struct FrontK {
+    const float* img;      // [B,H,W,3] f32
+    const u32x4* w0;       // stem weights [32 cout][32 k] bf16, k = (ky*3+kx)*3 + c, BN folded
+    const float* b0;       // [32]
+    const char* w1;        // [>=64 cout][w1_row bytes] bf16, k = (ky*3+kx)*32 + ci, BN folded
+    const float* b1;       // [64]
+    char* out;             // [B,H/2,W/2,out_ld] bf16 (+ out_coff channels)
+    int B, H, W, w1_row, out_ld, out_coff, act0, act1;
+    int tiles_x, tiles_y, ntiles;
+};
+
+template <int ACT>
+__device__ __forceinline__ float act(float v) {
+    if constexpr (ACT == 1) return 0.55f * v + 0.45f * __builtin_fabsf(v);       // model.py:8-12
+    else if constexpr (ACT == 2) return __builtin_fmaxf(0.1f * v, v);            // yolo_v2.py:86
+    else return v;
+}
+
+template <int TH, int ACT>
+__global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
+    constexpr int NT = 64 * TH, NW = TH;
+    constexpr int SH = 2 * TH + 1, SWH = 17;           // stem patch: SH x 33 pixels, x stored as (parity, x/2)
+    constexpr int IH = SH + 2, IROW = 105, IWP = 108;  // image patch: IH x 35 pixels x 3 floats, rows padded to 108
+    constexpr int IMG_BYTES = IH * IWP * 4;
+    constexpr int PLANE = SH * SWH * 16;               // one (chunk, parity) plane of the stem patch
+    constexpr int STEM_BYTES = 8 * PLANE;
+    constexpr int W1_ROW = 592, W1_BYTES = 64 * W1_ROW;
+    constexpr int ST_ROW = 144, ST_BYTES = TH * 16 * ST_ROW;
+    constexpr int NE = (IH * IROW + NT - 1) / NT;      // image floats per thread
+    constexpr int NG = SH + 1;                         // stem groups of 32 pixels: SH rows of x = 0..31, one of x = 32
+
+    static_assert(IMG_BYTES % 16 == 0 && (IMG_BYTES + STEM_BYTES + W1_BYTES + ST_BYTES) <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    float* const img = (float*)lds;
+    char* const stem = lds + IMG_BYTES;
+    char* const w1s = stem + STEM_BYTES;
+    char* const stage = w1s + W1_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+
+    // ---- once per workgroup: stride-2 conv weights -> LDS, stem weights / biases -> registers --------------
+    for (int i = tid; i < 64 * 36; i += NT) {          // 36 x 16 B per row of 288 bf16
+        const int row = i / 36, ch = i - row * 36;
+        *(u32x4*)(w1s + row * W1_ROW + ch * 16) = *(const u32x4*)(p.w1 + (long long)row * p.w1_row + ch * 16);
+    }
+    const bf16x8 wf0 = __builtin_bit_cast(bf16x8, p.w0[fr * 4 + fh]);        // A[row = cout fr][k = 8 fh + j]
+    const bf16x8 wf1 = __builtin_bit_cast(bf16x8, p.w0[fr * 4 + 2 + fh]);    //                  k = 16 + 8 fh + j
+    float b0v[16], b1v[16];
+    const int wm = wave >> 1, wn = wave & 1;           // conv phase: wave tile = 32 pixels (2 tile rows) x 32 channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        b0v[r] = p.b0[ch];
+        b1v[r] = p.b1[wn * 32 + ch];
+    }
+    // stem gather tables: this lane's 16 im2col taps k = 16 m + 8 fh + j as float offsets inside the image patch
+    int koff[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kq = 16 * m + 8 * fh + j;
+            const int ky = kq / 9;
+            koff[m][j] = kq < 27 ? ky * IWP + (kq - ky * 9) : 0;      // k >= 27: any finite value (its weight is 0)
+        }
+
+    auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        b = tile / per_img;
+        const int r = tile - b * per_img;
+        const int ty = r / p.tiles_x;
+        oy0 = ty * TH;
+        ox0 = (r - ty * p.tiles_x) * 16;
+    };
+    float pre[NE];
+    auto load_image_patch = [&](int tile) {            // global -> registers; out-of-image elements read a clamped pixel
+        int b, oy0, ox0;
+        tile_origin(tile, b, oy0, ox0);
+        const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * NT;
+            int iy = idx / IROW;
+            const int rx = idx - iy * IROW;
+            iy = iy < IH ? iy : IH - 1;
+            int gy = gy0 + iy, gx = gx0 + rx / 3;
+            gy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+            pre[e] = p.img[(((long long)b * p.H + gy) * p.W + gx) * 3 + rx % 3];
+        }
+    };
+    auto store_image_patch = [&](int tile) {           // registers -> LDS, zeros outside the image (the stem's SAME padding)
+        int b, oy0, ox0;
+        tile_origin(tile, b, oy0, ox0);
+        const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * NT;
+            const int iy = idx / IROW, rx = idx - iy * IROW;
+            const int gy = gy0 + iy, gx = gx0 + rx / 3;
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            if (idx < IH * IROW) img[iy * IWP + rx] = inside ? pre[e] : 0.f;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) {
+        load_image_patch(tile);
+        store_image_patch(tile);
+    }
+    __syncthreads();
+
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        int b, oy0, ox0;
+        tile_origin(tile, b, oy0, ox0);
+        const int next = tile + gridDim.x;
+        if (next < p.ntiles) load_image_patch(next);   // in flight during the two compute phases
+
+        // ---- stem: groups of 32 stem pixels --------------------------------------------------------------
+        for (int g = wave; g < NG; g += NW) {
+            // gather side: pixel = lane & 31
+            const bool pv = g < SH || fr < SH;
+            const int sy = g < SH ? g : (pv ? fr : 0);       // lanes past the column group read row 0, unused
+            const int sx = g < SH ? fr : 32;
+            const float* base = img + sy * IWP + sx * 3;
+            float gv[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gv[0][j] = base[koff[0][j]];
+                gv[1][j] = base[koff[1][j]];
+            }
+            bf16x8 a0, a1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a0[j] = (__bf16)gv[0][j];
+                a1[j] = (__bf16)gv[1][j];
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, a0, acc, 0, 0, 0);     // rows = channels, cols = pixels
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, a1, acc, 0, 0, 0);
+            // stem pixels outside the image are the stride-2 conv's zero padding (only row/column -1 can occur)
+            const bool outside = (oy0 == 0 && sy == 0) || (ox0 == 0 && sx == 0);
+            if (pv) {
+                char* dst = stem + (((sx & 1) * SH + sy) * SWH + (sx >> 1)) * 16 + fh * 8;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {          // channels 8q + 4fh .. +3 -> chunk q, bytes fh*8..
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(outside ? 0.f : act<ACT>(acc[4 * q + i] + b0v[4 * q + i]));
+                    *(bf16x4*)(dst + q * 2 * PLANE) = o;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- stride-2 conv out of the stem patch: A = weights (32 couts of this wave), B = 32 pixels ----------
+        {
+            const int ty = wm * 2 + (fr >> 4), tx = fr & 15;
+            const char* wrow = w1s + (wn * 32 + fr) * W1_ROW + fh * 16;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // fragments of tap t+1 are read while the two MFMAs of tap t run (static register sets)
+            bf16x8 af[2][2], bfr[2][2];
+            auto read_tap = [&](int t, int set) {
+                const int ky = t / 3, kx = t % 3;
+                // pixel (2ty + ky, 2tx + kx): parity kx & 1, x/2 = tx + (kx >> 1)
+                const char* px = stem + (((kx & 1) * SH + 2 * ty + ky) * SWH + tx + (kx >> 1)) * 16;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {       // channel halves: chunk = 2 hh + fh
+                    bfr[set][hh] = *(const bf16x8*)(px + (2 * hh + fh) * 2 * PLANE);
+                    af[set][hh] = *(const bf16x8*)(wrow + (t * 2 + hh) * 32);
+                }
+            };
+            read_tap(0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) read_tap(t + 1, (t + 1) & 1);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][hh], bfr[t & 1][hh], acc, 0, 0, 0);
+            }
+            // bias + leaky -> staging [pixel][64 ch] bf16 (row stride 144 B)
+            char* dst = stage + (wm * 32 + fr) * ST_ROW + (wn * 32 + 4 * fh) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)act<ACT>(acc[4 * q + i] + b1v[4 * q + i]);
+                *(bf16x4*)(dst + q * 16) = o;
+            }
+        }
+        __syncthreads();                               // staging complete; img and stem patch are free again
+
+        if (next < p.ntiles) store_image_patch(next);
+        // ---- stores: 8 x 16 B per pixel, pixels of a tile row contiguous in memory ----------------------------
+#pragma unroll
+        for (int it = 0; it < (TH * 16 * 8) / NT; ++it) {
+            const int idx = tid + it * NT;
+            const int pix = idx >> 3, ch = idx & 7;
+            const int py = pix >> 4, pxx = pix & 15;
+            const u32x4 v = *(const u32x4*)(stage + pix * ST_ROW + ch * 16);
+            *(u32x4*)(p.out + ((((long long)b * Ho + oy0 + py) * Wo + ox0 + pxx) * p.out_ld + p.out_coff) * 2 + ch * 16) = v;
+        }
+        __syncthreads();                               // next image patch visible; staging free
+    }
+}
+
+// images [B,H,W,3] f32 -> out [B,H/2,W/2,64] bf16 = conv2d(conv2d(x, 32, 3), 64, 3, strides=2) of darknet53_body.
+// c0 / c1: the two layers' launch descriptions (packed weights, biases, activation); only c1's output geometry is used.
+int launch_front(const ConvLaunch& c0, const ConvLaunch& c1, hipStream_t stream) {
+    YOLO_REQUIRE(c0.Cin == 3 && c0.Cout == 32 && c0.ksize == 3 && c0.stride == 1 && c0.in_ld == 3 && c0.in_coff == 0 &&
+                 c1.Cin == 32 && c1.Cout == 64 && c1.ksize == 3 && c1.stride == 2 && !c1.res && !c1.upsample && !c1.out_f32 &&
+                 (c0.leaky == 1 || c0.leaky == 2) && c1.leaky == c0.leaky,
+                 YOLO_ERR_UNSUPPORTED, "front: only 3->32 (3x3 s1) followed by 32->64 (3x3 s2) is implemented");
+    YOLO_REQUIRE(c0.H % 32 == 0 && c0.W % 32 == 0 && c1.out_ld % 8 == 0 && c1.out_coff % 8 == 0 && c1.kpad_bytes >= 576,
+                 YOLO_ERR_SHAPE, "front: H, W must be multiples of 32");
+    constexpr int TH = 8;
+    FrontK k;
+    k.img = (const float*)c0.in; k.w0 = (const u32x4*)c0.w; k.b0 = c0.bias; k.w1 = (const char*)c1.w; k.b1 = c1.bias;
+    k.out = (char*)c1.out;
+    k.B = c0.B; k.H = c0.H; k.W = c0.W; k.w1_row = c1.kpad_bytes; k.out_ld = c1.out_ld; k.out_coff = c1.out_coff;
+    k.act0 = c0.leaky; k.act1 = c1.leaky;
+    k.tiles_x = (c0.W / 2) / 16; k.tiles_y = (c0.H / 2) / TH;
+    const long long nt = (long long)k.B * k.tiles_x * k.tiles_y;
+    YOLO_REQUIRE(nt < (1ll << 31), YOLO_ERR_SHAPE, "front: too many tiles");
+    k.ntiles = (int)nt;
+    int grid = 256;                                    // one workgroup per CU, each walks ntiles / 256 tiles
+    if (grid > k.ntiles) grid = k.ntiles;
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    YOLO_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_done[dev]) {
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)front_kernel<TH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, front_lds_bytes<TH>()));
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)front_kernel<TH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, front_lds_bytes<TH>()));
+        if (dev < 16) attr_done[dev] = true;
+    }
+    note_kernel("yolo::front_kernel<%d, %d>", TH, c0.leaky);
+    if (c0.leaky == 1) hipLaunchKernelGGL((front_kernel<TH, 1>), dim3(grid), dim3(64 * TH), front_lds_bytes<TH>(), stream, k);
+    else hipLaunchKernelGGL((front_kernel<TH, 2>), dim3(grid), dim3(64 * TH), front_lds_bytes<TH>(), stream, k);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+}  // namespace yolo

@@ -2,6 +2,7 @@
 // the static execution plan of yolov3.forward (reference yolo_v3/model.py:21-67 +
 // yolo_v3/utils/layer_utils.py:23-72) and the C-ABI entry points for the conv stack.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -136,6 +137,27 @@ static int pack_conv(ConvParams& L, WAt w_at, const float* p0, const float* p1, 
     std::vector<float> scale, bias;
     fold_bn(L.cout, L.bn, p0, p1, p2, p3, scale, bias);
     return pack_conv_sb(L, w_at, scale, bias);
+}
+
+static void fill_conv(const ConvParams& L, ConvLaunch& p) {
+    p.w = L.w;
+    p.bias = L.bias;
+    p.Cin = L.cin;
+    p.Cout = L.cout;
+    p.ksize = L.k;
+    p.stride = L.stride;
+    p.pad = (L.k - 1) / 2;
+    p.kpad_bytes = L.kpad_bytes;
+    p.Ho = (p.H + 2 * p.pad - L.k) / L.stride + 1;
+    p.Wo = (p.W + 2 * p.pad - L.k) / L.stride + 1;
+    p.leaky = L.bn ? L.act : 0;
+}
+
+// conv2d(conv2d(x, 32, 3), 64, 3, strides=2) of darknet53_body (layer_utils.py:31-32) as one kernel
+static int run_front(const ConvParams& L0, const ConvParams& L1, ConvLaunch p0, ConvLaunch p1, hipStream_t stream) {
+    fill_conv(L0, p0);
+    fill_conv(L1, p1);
+    return launch_front(p0, p1, stream);
 }
 
 static int run_conv(const ConvParams& L, ConvLaunch p, hipStream_t stream) {
@@ -487,6 +509,14 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
     float* fms[3] = {fm1, fm2, fm3};
     int h_in = H, w_in = W;
     (void)h_in; (void)w_in;
+    // bf16 YOLOv3: the stem and the first stride-2 conv run as ONE kernel; the stem output tensor of the plan stays
+    // unused (YOLO_NO_FRONT_FUSION=1 in the environment keeps them apart, for A/B measurements)
+    static const bool no_fusion = [] { const char* e = getenv("YOLO_NO_FRONT_FUSION"); return e && atoi(e) != 0; }();
+    const bool fuse_front = net->kind == 3 && net->dtype == YOLO_DTYPE_BF16 && !no_fusion && P->steps.size() > 2 &&
+                            P->steps[0].layer == 0 && P->steps[1].layer == 1 && P->steps[1].in == P->steps[0].out &&
+                            P->steps[1].res < 0;
+    ConvLaunch front_p;
+    memset(&front_p, 0, sizeof(front_p));
     for (const Step& st : P->steps) {
         if (st.layer < 0) {                       // pooling_layer (yolo_v2.py:91-94)
             const Tens& ti = P->tens[st.in];
@@ -516,6 +546,19 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
         p.upsample = st.upsample;
         p.reorg = st.reorg;
         if (events) YOLO_HIP_CHECK(hipEventRecord(events[st.layer], (hipStream_t)stream));
+        if (fuse_front && st.layer == 0) {        // held back: launched together with layer 1 (front.hip)
+            front_p = p;
+            continue;
+        }
+        if (fuse_front && st.layer == 1) {
+            rc = run_front(*net->layers[0], L, front_p, p, (hipStream_t)stream);
+            if (rc != YOLO_OK) return rc;
+            if (record_kernel_names) {
+                net->kernel_names[0] = "(fused into layer 1)";     // its event pair brackets nothing
+                net->kernel_names[1] = last_kernel_name();
+            }
+            continue;
+        }
         rc = run_conv(L, p, (hipStream_t)stream);
         if (rc != YOLO_OK) return rc;
         if (record_kernel_names) net->kernel_names[st.layer] = last_kernel_name();
