@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run)
 
 A step = one pass of the hot path over one batch of 64 synthetic 416x416 images per GPU that are
-already resident in HBM: yolov3.forward (bf16 MFMA conv stack) -> predict (+ fused conf*prob) ->
-per-class NMS (gpu_nms defaults 50 / 0.5 / 0.5).  Images are independent, so ranks share nothing
+already resident in HBM: yolov3.forward (bf16 MFMA conv stack) -> predict -> conf*prob -> per-class NMS
+(gpu_nms defaults 50 / 0.5 / 0.5; the three post-processing steps run fused, yolo_detect_post).  Images are independent, so ranks share nothing
 (weak scaling, no collective in the timed region).  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -96,7 +96,6 @@ def main():
 
     from yolo_amd.model import yolov3
     from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
-    from yolo_amd.utils.nms_utils import gpu_nms_batched
     from yolo_amd.weights import synth_darknet_stream
 
     B, S = args.batch, args.size
@@ -106,9 +105,8 @@ def main():
     images = torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).cuda()
 
     def step():
-        fms = net.forward(images)
-        boxes, _, _, scores = net.predict(fms, return_scores=True)
-        return gpu_nms_batched(boxes, scores, 80, 50, 0.5, 0.5)
+        # forward -> predict -> conf*prob -> per-class NMS (gpu_nms defaults), the last three as one library call
+        return net.detect(images, 50, 0.5, 0.5)
 
     def barrier():
         torch.cuda.synchronize()

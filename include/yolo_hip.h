@@ -118,6 +118,17 @@ int yolo_nms(const float* boxes, const float* scores, int B, int n, int class_nu
              int32_t* out_labels, int32_t* out_index, int32_t* out_counts, void* workspace,
              size_t workspace_bytes, void* stream);
 
+/* ---- the post-processing chain of the driver in ONE call: replaces predict (yolo_v3/model.py:110-153), the
+ * caller's pred_confs * pred_probs (yolo_v3/test_single_image.py:38) and gpu_nms (yolo_v3/utils/nms_utils.py:7-37),
+ * applied to each of the B images independently.  Decode, score product and the score mask run as one pass over
+ * the feature maps; the [B,n,C] probs / scores tensors are never materialised.  Outputs as yolo_nms (mode
+ * YOLO_NMS_TF); results are bit-identical to yolo_decode (with scores) followed by yolo_nms. */
+size_t yolo_detect_post_workspace_bytes(int B, int H, int W, int class_num, int max_boxes);
+int yolo_detect_post(const float* fm1, const float* fm2, const float* fm3, int B, int H, int W, int class_num,
+                     const float* anchors, int max_boxes, float score_thresh, float iou_thresh, float* out_boxes,
+                     float* out_scores, int32_t* out_labels, int32_t* out_index, int32_t* out_counts,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- YOLOv2 (config 4).  yolo2_net_create/forward replace yolo_v2.build_networks + conv_layer + pooling_layer +
  * reorg (yolo_v2/yolo/yolo_v2.py:32-113).  vars: HOST float32, the TF variables concatenated in creation order per
  * conv (yolo_v2.py:75-83): weight [k,k,cin,cout], biases, then (batch-norm layers) scale, shift, rolling_mean,

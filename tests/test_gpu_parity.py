@@ -419,3 +419,48 @@ def test_detect_end_to_end_vs_oracle(net_f32, oracle, oracle_params):
     _, _, rl2, ri2 = oracle.gpu_nms(b, c * p, 80, 30, 0.4, 0.5, return_indices=True)
     ref = {(int(l), int(i)) for l, i in zip(rl2, ri2)}
     assert len(got & ref) >= 0.97 * len(ref), (len(got), len(ref), len(got & ref))
+
+
+def test_detect_post_fused_equals_separate_calls(net_bf16, net_f32):
+    """yolo_detect_post (decode + score + mask + NMS in one call) == predict -> conf*prob -> gpu_nms_batched,
+    bit for bit, at batch 8 / 416 and at a second shape, several thresholds (incl. the eval-style low one)."""
+    import torch
+    rng = np.random.default_rng(17)
+    for net, B, size in ((net_bf16, 8, 416), (net_f32, 2, 96)):
+        x = rng.random((B, size, size, 3), dtype=np.float32)
+        fms = net.forward(x)
+        for mb, st, it in ((50, 0.5, 0.5), (30, 0.4, 0.5), (20, 0.01, 0.45)):
+            from yolo_amd.utils.nms_utils import gpu_nms_batched
+            boxes, _, _, scores = net.predict(fms, return_scores=True)
+            ref = gpu_nms_batched(boxes, scores, net.class_num, mb, st, it)
+            got = net.postprocess(fms, mb, st, it)
+            assert torch.equal(ref[4], got[4])
+            assert st > 0.1 or int(ref[4].sum()) > 0
+            for b in range(B):
+                m = int(ref[4][b])
+                for r, g in zip(ref[:4], got[:4]):
+                    assert torch.equal(r[b, :m], g[b, :m])
+
+
+def test_detect_post_argument_errors(net_f32):
+    with pytest.raises(ValueError):
+        net_f32.postprocess([np.zeros((1, 2, 2, 255), np.float32), np.zeros((1, 4, 4, 255), np.float32),
+                             np.zeros((1, 8, 8, 255), np.float32)], max_boxes=0)
+
+
+def test_front_fusion_equals_separate_kernels(net_bf16):
+    """bf16: the fused stem + first stride-2 conv kernel (front.hip) gives the feature maps of the two separate
+    kernels bit for bit (same products, same accumulation order, same activation rounding)."""
+    import os
+    import torch
+    rng = np.random.default_rng(23)
+    for B, H, W in ((2, 416, 416), (1, 64, 96), (3, 32, 32)):
+        x = rng.random((B, H, W, 3), dtype=np.float32)
+        fused = [f.clone() for f in net_bf16.forward(x)]
+        os.environ["YOLO_NO_FRONT_FUSION"] = "1"
+        try:
+            plain = [f.clone() for f in net_bf16.forward(x)]
+        finally:
+            del os.environ["YOLO_NO_FRONT_FUSION"]
+        for a, b in zip(fused, plain):
+            assert torch.equal(a, b), float((a - b).abs().max())

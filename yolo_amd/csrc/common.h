@@ -29,6 +29,11 @@ void set_error(const char* fmt, ...);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// leaky_relu of the reference (yolo_v3/model.py:8-12): f1*x + f2*|x| with f1 = 0.55, f2 = 0.45.  Written as ONE
+// explicit fma so that every kernel (and the fused / unfused variants of a layer) rounds it the same way,
+// whatever the compiler would contract.
+__device__ __forceinline__ float leaky_v3(float v) { return __builtin_fmaf(0.45f, __builtin_fabsf(v), 0.55f * v); }
+
 // ---- conv layer launch description (device pointers) ------------------------------------
 struct ConvLaunch {
     const void* in;        // activations, element type = net dtype (stem: always f32)

@@ -80,7 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 float v = acc[i][j][r] + bv;
-                if (p.leaky == 1) v = 0.55f * v + 0.45f * __builtin_fabsf(v);
+                if (p.leaky == 1) v = leaky_v3(v);
                 else if (p.leaky == 2) v = __builtin_fmaxf(0.1f * v, v);
                 ct[row * LDC + col] = v;
             }

@@ -7,27 +7,9 @@
 // (y, x, anchor) box order (model.py:81,123-125), so thread e of image b maps 1:1 to input element
 // e of that image's scale-concatenated [n][5+C] view: reads are perfectly contiguous.
 #include <cstring>
-#include "common.h"
+#include "decode_common.h"
 
 namespace yolo {
-
-struct DecodeK {
-    const float* fm[3];
-    float* boxes;
-    float* confs;
-    float* probs;
-    float* scores;
-    int n, C, A;          // boxes per image, classes, attrs = 5 + C
-    int corners;          // 1: x_min,y_min,x_max,y_max (predict) ; 0: cx,cy,w,h (reorg_layer)
-    int off[4];           // first box of each scale, off[3] = n
-    int gw[3], gh[3];
-    float rw[3], rh[3];   // ratio (model.py:78): img / grid
-    float aw[3][3], ah[3][3];   // rescaled anchors (model.py:80): anchor / ratio
-};
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-// conf / prob path (95 % of the elements): v_exp_f32 + v_rcp_f32, ~2 ulp - far inside the 1e-3 budget
-__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 
 __global__ __launch_bounds__(256) void decode_kernel(DecodeK k) {
     const int b = blockIdx.y;
@@ -53,25 +35,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeK k) {
         } else if (attr == 4) {
             k.confs[jb] = sigmoid_fast(row[4]);                          // model.py:134
         } else {
-            const int cell = local / 3;
-            const int a = local - cell * 3;
-            const int y = cell / k.gw[s];
-            const int x = cell - y * k.gw[s];
-            const bool isx = (attr & 1) == 0;                            // attr 0,2 -> x ; 1,3 -> y
-            const float t_c = isx ? row[0] : row[1];
-            const float t_s = isx ? row[2] : row[3];
-            const float ratio = isx ? k.rw[s] : k.rh[s];
-            const float anc = isx ? k.aw[s][a] : k.ah[s][a];
-            const float g = isx ? (float)x : (float)y;
-            const float c = __fmul_rn(__fadd_rn(sigmoidf_(t_c), g), ratio);                  // model.py:88,99,101
-            const float ex = fminf(fmaxf(expf(t_s), 1e-9f), 50.0f);                          // model.py:103
-            const float sz = __fmul_rn(__fmul_rn(ex, anc), ratio);                           // model.py:103,105
-            if (k.corners) {
-                const float half = sz / 2.0f;                                                // model.py:148-151
-                k.boxes[jb * 4 + attr] = attr < 2 ? __fsub_rn(c, half) : __fadd_rn(c, half);
-            } else {
-                k.boxes[jb * 4 + attr] = attr < 2 ? c : sz;                                  // model.py:107
-            }
+            k.boxes[jb * 4 + attr] = decode_box_attr(k, s, local, row, attr);
         }
     }
 }
@@ -87,23 +51,7 @@ extern "C" int yolo_decode(const float* fm1, const float* fm2, const float* fm3,
     DecodeK k;
     k.fm[0] = fm1; k.fm[1] = fm2; k.fm[2] = fm3;
     k.boxes = boxes; k.confs = confs; k.probs = probs; k.scores = scores;
-    k.C = class_num; k.A = 5 + class_num;
-    int off = 0;
-    for (int s = 0; s < 3; ++s) {
-        const int r = 32 >> s;
-        k.gh[s] = H / r; k.gw[s] = W / r;
-        k.off[s] = off;
-        off += k.gh[s] * k.gw[s] * 3;
-        // model.py:78: ratio = cast(img_size / grid_size, float32)  (true division in float64, then cast)
-        k.rh[s] = (float)((double)H / k.gh[s]);
-        k.rw[s] = (float)((double)W / k.gw[s]);
-        const float* anc = anchors + 2 * 3 * (2 - s);           // model.py:116-118: fm1 <- anchors[6:9] ...
-        for (int a = 0; a < 3; ++a) {
-            k.aw[s][a] = anc[2 * a] / k.rw[s];                  // model.py:80 (float32 / float32)
-            k.ah[s][a] = anc[2 * a + 1] / k.rh[s];
-        }
-    }
-    k.off[3] = off; k.n = off; k.corners = 1;
+    decode_setup(k, H, W, class_num, anchors);
     const long long per_img = (long long)k.n * k.A;
     YOLO_REQUIRE(per_img < (1ll << 24), YOLO_ERR_SHAPE, "decode: more than 2^24 elements per image");
     unsigned gx = (unsigned)((per_img + 255) / 256);

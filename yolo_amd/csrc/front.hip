@@ -16,6 +16,7 @@
 //   3. stride-2 conv as an implicit GEMM out of LDS: per wave 32 pixels x 32 channels, 18 k-slices (9 taps x 2 channel
 //      halves); weights [64][288] bf16 staged once per workgroup (row stride 592 B: conflict-free fragment reads).
 //   4. bias + leaky -> bf16 -> LDS staging -> 16-byte stores, 128 contiguous bytes per pixel.
+#include <cstdlib>
 #include "common.h"
 
 namespace yolo {
@@ -42,7 +43,7 @@ struct FrontK {
 
 template <int ACT>
 __device__ __forceinline__ float act(float v) {
-    if constexpr (ACT == 1) return 0.55f * v + 0.45f * __builtin_fabsf(v);       // model.py:8-12
+    if constexpr (ACT == 1) return leaky_v3(v);                                  // model.py:8-12
     else if constexpr (ACT == 2) return __builtin_fmaxf(0.1f * v, v);            // yolo_v2.py:86
     else return v;
 }
@@ -243,6 +244,23 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
     }
 }
 
+template <int TH>
+static int launch_front_th(const FrontK& k, int grid, int act_mode, hipStream_t stream) {
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    YOLO_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_done[dev]) {
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)front_kernel<TH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, front_lds_bytes<TH>()));
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)front_kernel<TH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, front_lds_bytes<TH>()));
+        if (dev < 16) attr_done[dev] = true;
+    }
+    note_kernel("yolo::front_kernel<%d, %d>", TH, act_mode);
+    if (act_mode == 1) hipLaunchKernelGGL((front_kernel<TH, 1>), dim3(grid), dim3(64 * TH), front_lds_bytes<TH>(), stream, k);
+    else hipLaunchKernelGGL((front_kernel<TH, 2>), dim3(grid), dim3(64 * TH), front_lds_bytes<TH>(), stream, k);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
 // images [B,H,W,3] f32 -> out [B,H/2,W/2,64] bf16 = conv2d(conv2d(x, 32, 3), 64, 3, strides=2) of darknet53_body.
 // c0 / c1: the two layers' launch descriptions (packed weights, biases, activation); only c1's output geometry is used.
 int launch_front(const ConvLaunch& c0, const ConvLaunch& c1, hipStream_t stream) {
@@ -252,31 +270,23 @@ int launch_front(const ConvLaunch& c0, const ConvLaunch& c1, hipStream_t stream)
                  YOLO_ERR_UNSUPPORTED, "front: only 3->32 (3x3 s1) followed by 32->64 (3x3 s2) is implemented");
     YOLO_REQUIRE(c0.H % 32 == 0 && c0.W % 32 == 0 && c1.out_ld % 8 == 0 && c1.out_coff % 8 == 0 && c1.kpad_bytes >= 576,
                  YOLO_ERR_SHAPE, "front: H, W must be multiples of 32");
-    constexpr int TH = 8;
+    static const int th_env = [] { const char* e = getenv("YOLO_FRONT_TH"); return e ? atoi(e) : 0; }();
+    static const int bpc_env = [] { const char* e = getenv("YOLO_FRONT_BPC"); return e ? atoi(e) : 0; }();
+    const int th = th_env == 4 ? 4 : 8;
     FrontK k;
     k.img = (const float*)c0.in; k.w0 = (const u32x4*)c0.w; k.b0 = c0.bias; k.w1 = (const char*)c1.w; k.b1 = c1.bias;
     k.out = (char*)c1.out;
     k.B = c0.B; k.H = c0.H; k.W = c0.W; k.w1_row = c1.kpad_bytes; k.out_ld = c1.out_ld; k.out_coff = c1.out_coff;
     k.act0 = c0.leaky; k.act1 = c1.leaky;
-    k.tiles_x = (c0.W / 2) / 16; k.tiles_y = (c0.H / 2) / TH;
+    k.tiles_x = (c0.W / 2) / 16; k.tiles_y = (c0.H / 2) / th;
     const long long nt = (long long)k.B * k.tiles_x * k.tiles_y;
     YOLO_REQUIRE(nt < (1ll << 31), YOLO_ERR_SHAPE, "front: too many tiles");
     k.ntiles = (int)nt;
-    int grid = 256;                                    // one workgroup per CU, each walks ntiles / 256 tiles
+    // persistent workgroups: as many as fit a CU's LDS (TH = 8: one of 8 waves, TH = 4: two of 4 waves), each walks
+    // ntiles / grid tiles
+    int grid = 256 * (bpc_env > 0 ? bpc_env : (th == 4 ? 2 : 1));
     if (grid > k.ntiles) grid = k.ntiles;
-    static bool attr_done[16] = {false};
-    int dev = 0;
-    YOLO_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 16 || !attr_done[dev]) {
-        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)front_kernel<TH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, front_lds_bytes<TH>()));
-        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)front_kernel<TH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, front_lds_bytes<TH>()));
-        if (dev < 16) attr_done[dev] = true;
-    }
-    note_kernel("yolo::front_kernel<%d, %d>", TH, c0.leaky);
-    if (c0.leaky == 1) hipLaunchKernelGGL((front_kernel<TH, 1>), dim3(grid), dim3(64 * TH), front_lds_bytes<TH>(), stream, k);
-    else hipLaunchKernelGGL((front_kernel<TH, 2>), dim3(grid), dim3(64 * TH), front_lds_bytes<TH>(), stream, k);
-    YOLO_HIP_CHECK(hipGetLastError());
-    return YOLO_OK;
+    return th == 4 ? launch_front_th<4>(k, grid, c0.leaky, stream) : launch_front_th<8>(k, grid, c0.leaky, stream);
 }
 
 }  // namespace yolo

@@ -511,7 +511,8 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
     (void)h_in; (void)w_in;
     // bf16 YOLOv3: the stem and the first stride-2 conv run as ONE kernel; the stem output tensor of the plan stays
     // unused (YOLO_NO_FRONT_FUSION=1 in the environment keeps them apart, for A/B measurements)
-    static const bool no_fusion = [] { const char* e = getenv("YOLO_NO_FRONT_FUSION"); return e && atoi(e) != 0; }();
+    const char* nf_env = getenv("YOLO_NO_FRONT_FUSION");   // read per call: the tests toggle it
+    const bool no_fusion = nf_env && atoi(nf_env) != 0;
     const bool fuse_front = net->kind == 3 && net->dtype == YOLO_DTYPE_BF16 && !no_fusion && P->steps.size() > 2 &&
                             P->steps[0].layer == 0 && P->steps[1].layer == 1 && P->steps[1].in == P->steps[0].out &&
                             P->steps[1].res < 0;

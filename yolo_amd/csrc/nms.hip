@@ -18,7 +18,7 @@
 //                    every pass kills what the last selected box suppresses and min-reduces the
 //                    surviving keys; at most max_boxes passes, no sort.
 //  3. nms_gather  : per image, prefix over class counts -> class-ordered dense output rows.
-#include "common.h"
+#include "decode_common.h"
 
 namespace yolo {
 
@@ -78,6 +78,12 @@ __device__ __forceinline__ unsigned key_index(u64 key) {
     return MODE == YOLO_NMS_TF ? lo : ~lo;
 }
 
+// score stored in a candidate key (inverse of make_key's monotone map)
+__device__ __forceinline__ float key_score(u64 key) {
+    const unsigned u = ~(unsigned)(key >> 32);
+    return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
 // ---- 1. compaction -----------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restrict__ scores, int n, int C, float thr,
@@ -116,12 +122,66 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
     }
 }
 
+// ---- 1b. decode + score + compaction in one pass (yolo_detect_post) ----------------------------------------
+// The chain predict -> pred_confs * pred_probs -> score mask of gpu_nms (reference yolo_v3/model.py:110-153,
+// yolo_v3/test_single_image.py:38, yolo_v3/utils/nms_utils.py:22) without the [B,n,C] probs / scores tensors ever
+// reaching HBM: a tile of 128 boxes x (5+C) logits is read once (contiguous), sigmoid-ed into LDS, the four box
+// attributes are decoded and stored, and every class column is compacted into candidate keys exactly as
+// nms_compact_kernel does.  The score of a candidate is sigmoid_fast(t4) * sigmoid_fast(t5+c), the expression
+// decode_kernel evaluates, so keys (and therefore the NMS result) are bit-identical to the unfused path.
+template <int MODE>
+__global__ __launch_bounds__(256) void decode_compact_kernel(DecodeK k, float thr, int* __restrict__ cand_count,
+                                                             u64* __restrict__ cand_keys) {
+    extern __shared__ float dtile[];            // [kTileJ][ldt]
+    const int b = blockIdx.y;
+    const int j0 = blockIdx.x * kTileJ;
+    const int nj = min(kTileJ, k.n - j0);
+    const int A = k.A, C = k.C;
+    const int ldt = A | 1;                      // odd stride: column reads are bank-conflict free
+    const float inv_a = 1.0f / (float)A;
+    for (int e = threadIdx.x; e < nj * A; e += 256) {
+        int j = (int)((float)e * inv_a);
+        int attr = e - j * A;
+        if (attr < 0) { attr += A; --j; }
+        if (attr >= A) { attr -= A; ++j; }
+        const int jg = j0 + j;
+        const int s = (jg >= k.off[1]) + (jg >= k.off[2]);
+        const int ns = k.off[s + 1] - k.off[s];
+        const float v = k.fm[s][((long long)b * ns + (jg - k.off[s])) * A + attr];
+        dtile[j * ldt + attr] = attr < 4 ? v : sigmoid_fast(v);            // model.py:134-135
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nj * 4; e += 256) {                      // boxes (model.py:76-108,147-152)
+        const int j = e >> 2, attr = e & 3;
+        const int jg = j0 + j;
+        const int s = (jg >= k.off[1]) + (jg >= k.off[2]);
+        k.boxes[((long long)b * k.n + jg) * 4 + attr] = decode_box_attr(k, s, jg - k.off[s], dtile + j * ldt, attr);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C; c += 4) {
+        int* cnt = cand_count + (long long)b * C + c;
+        u64* keys = cand_keys + ((long long)b * C + c) * k.n;
+#pragma unroll
+        for (int h = 0; h < kTileJ / 64; ++h) {
+            const int j = h * 64 + lane;
+            const float s = j < nj ? dtile[j * ldt + 4] * dtile[j * ldt + 5 + c] : 0.f;   // test_single_image.py:38
+            const bool pass = j < nj && s >= thr;                        // nms_utils.py:22
+            const u64 m = __ballot(pass);
+            if (m == 0) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(cnt, __popcll(m));
+            base = __shfl(base, 0);
+            if (pass) keys[base + __popcll(m & ((1ull << lane) - 1))] = make_key<MODE>(s, (unsigned)(j0 + j));
+        }
+    }
+}
+
 // ---- 2. selection ------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict__ boxes, int n, int C, int max_boxes,
                                                          float iou_thr, const int* __restrict__ cand_count,
                                                          u64* __restrict__ cand_keys, int* __restrict__ sel_count,
-                                                         int* __restrict__ sel_idx) {
+                                                         int* __restrict__ sel_idx, float* __restrict__ sel_score) {
     __shared__ u64 skeys[kSortCap];
     __shared__ f32x4 selbox[kSelCap];
     __shared__ u64 masks[64];
@@ -133,6 +193,7 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
     const int k = cand_count[bc];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* out_idx = sel_idx + (long long)bc * max_boxes;
+    float* out_sc = sel_score ? sel_score + (long long)bc * max_boxes : nullptr;   // scores live only in the keys (fused path)
     const f32x4* bx = (const f32x4*)boxes + (long long)b * n;
     u64* keys = cand_keys + (long long)bc * n;
     if (k == 0) {
@@ -162,7 +223,8 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
         for (int c0 = 0; c0 < k && nsel < max_boxes; c0 += 64) {
             const int i = c0 + lane;
             const bool valid = i < k;
-            const unsigned idx = valid ? key_index<MODE>(skeys[i]) : 0u;
+            const u64 mykey = valid ? skeys[i] : 0ull;
+            const unsigned idx = valid ? key_index<MODE>(mykey) : 0u;
             f32x4 box = {0.f, 0.f, 0.f, 0.f};
             if (valid) box = bx[idx];
             bool alive = valid;
@@ -190,6 +252,7 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
                 const int pos = nsel + __popcll(selected & ((1ull << lane) - 1));
                 selbox[pos] = box;
                 out_idx[pos] = (int)idx;
+                if (out_sc) out_sc[pos] = key_score(mykey);
             }
             nsel = cnt;
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -233,7 +296,10 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
         const unsigned idx = key_index<MODE>(selkey);
         sbox = bx[idx];
         have = true;
-        if (tid == 0) out_idx[nsel] = (int)idx;
+        if (tid == 0) {
+            out_idx[nsel] = (int)idx;
+            if (out_sc) out_sc[nsel] = key_score(selkey);
+        }
         ++nsel;
         if (nsel >= max_boxes) break;
     }
@@ -243,7 +309,8 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
 // ---- 3. class-ordered dense output ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                          int n, int C, int max_boxes, const int* __restrict__ sel_count,
-                                                         const int* __restrict__ sel_idx, float* __restrict__ out_boxes,
+                                                         const int* __restrict__ sel_idx, const float* __restrict__ sel_score,
+                                                         float* __restrict__ out_boxes,
                                                          float* __restrict__ out_scores, int* __restrict__ out_labels,
                                                          int* __restrict__ out_index, int* __restrict__ out_counts) {
     extern __shared__ int prefix[];            // [C + 1]
@@ -262,13 +329,14 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict
         const int idx = sel_idx[((long long)b * C + c) * max_boxes + r];
         const long long o = row0 + prefix[c] + r;
         ((f32x4*)out_boxes)[o] = ((const f32x4*)boxes)[(long long)b * n + idx];      // nms_utils.py:32
-        out_scores[o] = scores[((long long)b * n + idx) * C + c];                    // nms_utils.py:33
+        out_scores[o] = scores ? scores[((long long)b * n + idx) * C + c]            // nms_utils.py:33
+                               : sel_score[((long long)b * C + c) * max_boxes + r];
         out_labels[o] = c;                                                           // nms_utils.py:31
         if (out_index) out_index[o] = idx;
     }
 }
 
-struct NmsWs { int* cand_count; int* sel_count; int* sel_idx; u64* cand_keys; size_t total; };
+struct NmsWs { int* cand_count; int* sel_count; int* sel_idx; u64* cand_keys; size_t total; float* sel_score; float* boxes; };
 
 static NmsWs nms_layout(void* base, int B, int n, int C, int max_boxes) {
     NmsWs w;
@@ -279,6 +347,19 @@ static NmsWs nms_layout(void* base, int B, int n, int C, int max_boxes) {
     w.sel_count = (int*)(p + off); off = align_up(off + bc * 4, 256);
     w.sel_idx = (int*)(p + off); off = align_up(off + bc * (size_t)max_boxes * 4, 256);
     w.cand_keys = (u64*)(p + off); off = align_up(off + bc * (size_t)n * 8, 256);
+    w.total = off;
+    w.sel_score = nullptr;
+    w.boxes = nullptr;
+    return w;
+}
+
+// yolo_detect_post: the NMS arrays + selected scores + decoded boxes [B,n,4]
+static NmsWs post_layout(void* base, int B, int n, int C, int max_boxes) {
+    NmsWs w = nms_layout(base, B, n, C, max_boxes);
+    char* p = (char*)base;
+    size_t off = w.total;
+    w.sel_score = (float*)(p + off); off = align_up(off + (size_t)B * C * max_boxes * 4, 256);
+    w.boxes = (float*)(p + off); off = align_up(off + (size_t)B * n * 16, 256);
     w.total = off;
     return w;
 }
@@ -292,10 +373,37 @@ static int nms_run(const float* boxes, const float* scores, int B, int n, int C,
     hipLaunchKernelGGL(nms_compact_kernel<MODE>, dim3(tiles, B, ctiles), dim3(256), 0, stream, scores, n, C, st, w.cand_count, w.cand_keys);
     YOLO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_select_kernel<MODE>, dim3((unsigned)(B * C)), dim3(256), 0, stream, boxes, n, C, max_boxes, it,
-                       w.cand_count, w.cand_keys, w.sel_count, w.sel_idx);
+                       w.cand_count, w.cand_keys, w.sel_count, w.sel_idx, (float*)nullptr);
     YOLO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, stream, boxes, scores, n, C, max_boxes,
-                       w.sel_count, w.sel_idx, ob, os, ol, oi, oc);
+                       w.sel_count, w.sel_idx, (const float*)nullptr, ob, os, ol, oi, oc);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
+// decode + score + compaction fused, then the same selection / gather kernels (TF semantics = gpu_nms)
+static int post_run(DecodeK k, int B, int max_boxes, float st, float it, float* ob, float* os, int* ol, int* oi, int* oc,
+                    const NmsWs& w, hipStream_t stream) {
+    const int n = k.n, C = k.C;
+    YOLO_HIP_CHECK(hipMemsetAsync(w.cand_count, 0, (size_t)B * C * 4, stream));
+    const unsigned tiles = (unsigned)((n + kTileJ - 1) / kTileJ);
+    const size_t lds = (size_t)kTileJ * (k.A | 1) * 4;
+    auto fn = decode_compact_kernel<YOLO_NMS_TF>;
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    YOLO_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_done[dev]) {
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev < 16) attr_done[dev] = true;
+    }
+    k.boxes = w.boxes;
+    hipLaunchKernelGGL(fn, dim3(tiles, B), dim3(256), lds, stream, k, st, w.cand_count, w.cand_keys);
+    YOLO_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(nms_select_kernel<YOLO_NMS_TF>, dim3((unsigned)(B * C)), dim3(256), 0, stream, w.boxes, n, C, max_boxes, it,
+                       w.cand_count, w.cand_keys, w.sel_count, w.sel_idx, w.sel_score);
+    YOLO_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, stream, w.boxes, (const float*)nullptr, n, C,
+                       max_boxes, w.sel_count, w.sel_idx, w.sel_score, ob, os, ol, oi, oc);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
 }
@@ -326,4 +434,34 @@ extern "C" int yolo_nms(const float* boxes, const float* scores, int B, int n, i
                                     out_labels, out_index, out_counts, w, (hipStream_t)stream);
     return nms_run<YOLO_NMS_PY>(boxes, scores, B, n, class_num, max_boxes, score_thresh, iou_thresh, out_boxes, out_scores,
                                 out_labels, out_index, out_counts, w, (hipStream_t)stream);
+}
+
+static int post_shape(int H, int W) { return 3 * ((H / 32) * (W / 32) + (H / 16) * (W / 16) + (H / 8) * (W / 8)); }
+
+extern "C" size_t yolo_detect_post_workspace_bytes(int B, int H, int W, int class_num, int max_boxes) {
+    if (B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32 || class_num <= 0 || max_boxes <= 0) return 0;
+    return yolo::post_layout(nullptr, B, post_shape(H, W), class_num, max_boxes).total;
+}
+
+extern "C" int yolo_detect_post(const float* fm1, const float* fm2, const float* fm3, int B, int H, int W, int class_num,
+                                const float* anchors, int max_boxes, float score_thresh, float iou_thresh, float* out_boxes,
+                                float* out_scores, int32_t* out_labels, int32_t* out_index, int32_t* out_counts,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace yolo;
+    YOLO_REQUIRE(fm1 && fm2 && fm3 && anchors && out_boxes && out_scores && out_labels && out_counts && workspace, YOLO_ERR_ARG,
+                 "detect_post: null pointer");
+    YOLO_REQUIRE(B > 0 && B <= 65535 && class_num > 0 && max_boxes > 0, YOLO_ERR_ARG, "detect_post: non-positive size");
+    YOLO_REQUIRE(H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, YOLO_ERR_SHAPE, "detect_post: H, W must be positive multiples of 32 (got %d x %d)", H, W);
+    YOLO_REQUIRE(max_boxes <= kSelCap, YOLO_ERR_UNSUPPORTED, "detect_post: max_boxes %d > %d", max_boxes, kSelCap);
+    YOLO_REQUIRE(class_num <= 250, YOLO_ERR_UNSUPPORTED, "detect_post: class_num %d > 250 (LDS tile); use yolo_decode + yolo_nms", class_num);
+    DecodeK k;
+    k.fm[0] = fm1; k.fm[1] = fm2; k.fm[2] = fm3;
+    k.boxes = nullptr; k.confs = nullptr; k.probs = nullptr; k.scores = nullptr;
+    decode_setup(k, H, W, class_num, anchors);
+    YOLO_REQUIRE((long long)k.n * k.A < (1ll << 24) && (long long)B * k.n < (1ll << 31), YOLO_ERR_SHAPE, "detect_post: problem too large");
+    const NmsWs w = post_layout(workspace, B, k.n, class_num, max_boxes);
+    YOLO_REQUIRE(workspace_bytes >= w.total, YOLO_ERR_WORKSPACE, "detect_post: workspace %zu < %zu bytes", workspace_bytes, w.total);
+    YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "detect_post: workspace must be 256-byte aligned");
+    return post_run(k, B, max_boxes, score_thresh, iou_thresh, out_boxes, out_scores, out_labels, out_index, out_counts, w,
+                    (hipStream_t)stream);
 }

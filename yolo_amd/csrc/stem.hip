@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
     }
     if (leaky == 1) {
 #pragma unroll
-        for (int n = 0; n < COUT; ++n) acc[n] = 0.55f * acc[n] + 0.45f * __builtin_fabsf(acc[n]);
+        for (int n = 0; n < COUT; ++n) acc[n] = leaky_v3(acc[n]);
     } else if (leaky == 2) {
 #pragma unroll
         for (int n = 0; n < COUT; ++n) acc[n] = __builtin_fmaxf(0.1f * acc[n], acc[n]);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
             float v = acc[r] + bv;
-            if (leaky == 1) v = 0.55f * v + 0.45f * __builtin_fabsf(v);
+            if (leaky == 1) v = leaky_v3(v);
             else if (leaky == 2) v = __builtin_fmaxf(0.1f * v, v);
             tl[row * 33 + fr] = v;
         }

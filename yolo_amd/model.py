@@ -27,6 +27,7 @@ class yolov3(object):
         self._dtype_code = _lib.DTYPES[dtype]
         self._net = None
         self._ws = None
+        self._post_ws = None
         self.img_size = None
 
     # ---- weights (replaces tf.train.Saver.restore at test_single_image.py:35-36) -----------------
@@ -106,7 +107,41 @@ class yolov3(object):
     def detect(self, inputs, max_boxes=30, score_thresh=0.4, iou_thresh=0.5):
         """The hot chain of test_single_image.py:31-40 for a batch, per image: forward -> predict ->
         conf*prob -> per-class NMS.  Defaults are that script's thresholds (:39).
-        -> (boxes [N,C*max_boxes,4], scores, labels int32, keep-index int32, counts int32 [N])."""
+        -> (boxes [N,C*max_boxes,4], scores, labels int32, keep-index int32, counts int32 [N]).
+        predict, the score product and gpu_nms run as ONE library call (yolo_detect_post): identical
+        results to the separate calls (detect_unfused), without the [N,n,C] probs / scores tensors."""
+        return self.postprocess(self.forward(inputs), max_boxes, score_thresh, iou_thresh)
+
+    def postprocess(self, feature_maps, max_boxes=30, score_thresh=0.4, iou_thresh=0.5):
+        fm1, fm2, fm3 = [_tensor.as_dev_f32(f) for f in feature_maps]
+        B = int(fm1.shape[0])
+        if self.img_size is None:
+            self.img_size = (int(fm1.shape[1]) * 32, int(fm1.shape[2]) * 32)
+        H, W = self.img_size
+        C = self.class_num
+        anc = np.ascontiguousarray(self.anchors, np.float32)
+        if anc.shape != (9, 2):
+            raise ValueError("detect needs 9 anchors, got %s" % (anc.shape,))
+        L = _lib.lib()
+        cap = C * int(max_boxes)
+        ob = _tensor.empty((B, cap, 4))
+        osc = _tensor.empty((B, cap))
+        ol = _tensor.empty((B, cap), torch.int32)
+        oi = _tensor.empty((B, cap), torch.int32)
+        oc = _tensor.empty((B,), torch.int32)
+        need = L.yolo_detect_post_workspace_bytes(B, H, W, C, int(max_boxes))
+        if need == 0:
+            raise ValueError("detect: bad sizes B=%d H=%d W=%d C=%d max_boxes=%d" % (B, H, W, C, max_boxes))
+        if self._post_ws is None or self._post_ws.numel() < need or self._post_ws.device != fm1.device:
+            self._post_ws = _tensor.workspace(need)
+        _lib.check(L.yolo_detect_post(fm1.data_ptr(), fm2.data_ptr(), fm3.data_ptr(), B, H, W, C, anc.ctypes.data,
+                                      int(max_boxes), float(score_thresh), float(iou_thresh), ob.data_ptr(),
+                                      osc.data_ptr(), ol.data_ptr(), oi.data_ptr(), oc.data_ptr(),
+                                      self._post_ws.data_ptr(), self._post_ws.numel(), _tensor.stream_ptr()))
+        return ob, osc, ol, oi, oc
+
+    def detect_unfused(self, inputs, max_boxes=30, score_thresh=0.4, iou_thresh=0.5):
+        """detect() written with the reference's separate calls (predict, conf*prob, per-image gpu_nms)."""
         from .utils.nms_utils import gpu_nms_batched
         fms = self.forward(inputs)
         boxes, _, _, scores = self.predict(fms, return_scores=True)
