@@ -410,7 +410,9 @@ extern "C" int yolo_debug_read_stamps(unsigned long long* host, int n) {
 // 9-bit mask.  Only the [BN x 128 B] weight tile is loaded per tap.  Global->LDS traffic per FLOP drops
 // ~2.4x (BM=256) against im2col at the same tile.
 // K order of the packed weights stays (ky,kx,ci); the loop order here is (ci-chunk, tap).
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N>
+// SPB (single patch buffer): the patch of the next channel chunk is loaded only after the last tap of the current
+// one (one exposed load latency per chunk) - half the patch LDS, so that two workgroups fit a CU at larger W.
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(ConvK p, int prows) {
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int NW = WARPS_M * WARPS_N;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
     const int nchunks = CinB >> 7;
     const int patch_bytes = prows * 128;          // prows: BM + 2W + 2 rounded up to 8
     char* const patch0 = lds;
-    char* const bbuf0 = lds + (nchunks > 1 ? 2 : 1) * patch_bytes;   // one patch buffer suffices for one chunk
+    char* const bbuf0 = lds + ((nchunks > 1 && !SPB) ? 2 : 1) * patch_bytes;   // one patch buffer suffices for one chunk
     char* const zrow = bbuf0 + 2 * B_BYTES;       // 128 zero bytes: source of out-of-image taps
     if (tid < 32) ((unsigned*)zrow)[tid] = 0u;    // ordered before the first fragment read by the loop's barrier
 
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
             int q = qlane + 8 * g;
             q = q < 0 ? 0 : (q >= p.M ? p.M - 1 : q);
             const unsigned off = (unsigned)q * pix_b + chunk * 16;
-            GLDS16(in_base + c * 128 + off, patch0 + (c & 1) * patch_bytes + g * 1024);
+            GLDS16(in_base + c * 128 + off, patch0 + (SPB ? 0 : (c & 1) * patch_bytes) + g * 1024);
         }
     };
     // weight tile of (chunk c, tap t) -> weight buffer `buf`
@@ -531,7 +533,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
     int bcur = 0;
     STAMP(0);
     for (int c = 0; c < nchunks; ++c) {
-        const char* patch = patch0 + (c & 1) * patch_bytes;
+        const char* patch = patch0 + (SPB ? 0 : (c & 1) * patch_bytes);
+        if (SPB && c > 0) {                    // every wave is done with chunk c-1: refill the single patch buffer
+            __builtin_amdgcn_s_barrier();
+            for (int sl = 0; sl < slots; ++sl) load_patch_piece(c, sl);
+        }
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
             // prefetch
             if (t < 8) load_b(c, t + 1, bcur ^ 1);
             else if (c + 1 < nchunks) load_b(c + 1, 0, bcur ^ 1);
-            if (c + 1 < nchunks)
+            if (!SPB && c + 1 < nchunks)
                 for (int sl = t; sl < slots; sl += 9) load_patch_piece(c + 1, sl);
             STAMP(3);
             // fragments of this tap
@@ -607,16 +613,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
 #endif
 }
 
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N>
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false>
 static int launch_halo(const ConvK& k, hipStream_t stream) {
     const int prows = (int)align_up((size_t)(BM + 2 * k.W + 2), 8);
     const int nchunks = k.Cin * (BF16 ? 2 : 4) / 128;
-    const int loop_bytes = (nchunks > 1 ? 2 : 1) * prows * 128 + 2 * BN * 128 + 128;
+    const int loop_bytes = ((nchunks > 1 && !SPB) ? 2 : 1) * prows * 128 + 2 * BN * 128 + 128;
     constexpr int epi_bytes = BM * (BN + 4) * 4;
     const int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
     YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 halo: W=%d needs %d bytes of LDS", k.W, lds_bytes);
     YOLO_REQUIRE((long long)k.M * k.in_ld * (BF16 ? 2 : 4) < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 halo: input larger than 4 GiB");
-    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N>;
+    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB>;
     static bool attr_done[16] = {false};
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
@@ -627,7 +633,7 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N);
+    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false");
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
@@ -675,6 +681,9 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         if (k.Cout <= 32) cfg = 10;
         else if (k.Cout <= 64) cfg = k.ksize == 1 ? 14 : 12;
         else if (halo_ok && k.W <= 32) cfg = 24;
+        // larger maps: a single patch buffer keeps two 128x128 workgroups per CU (measured 10 % faster than the
+        // 16-wave 256x128 workgroup at 52x52, 7 % at 104x104)
+        else if (halo_ok && (int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 80 * 1024) cfg = 28;
         else if (halo_ok && patch_bufs * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 26;
         else cfg = 5;
     }
@@ -692,6 +701,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 25: return launch_halo<BF16, 128, 128, 2, 4>(k, stream);
         case 26: return launch_halo<BF16, 256, 128, 8, 2>(k, stream);      // 16 waves, 1 block/CU
         case 27: return launch_halo<BF16, 256, 128, 4, 4>(k, stream);
+        case 28: return launch_halo<BF16, 128, 128, 4, 2, true>(k, stream);   // single patch buffer: 2 blocks/CU up to W ~ 60
         case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
