@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--layer-table", default="", help="write the per-layer timing table to this file")
+    ap.add_argument("--h2d", action="store_true", help="also report the rate with the batch copied from pinned host memory "
+                                                       "inside every step (extra key, never `value`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,6 +169,19 @@ def main():
                 f.write("%2d %4d %4d %d %d %8.4f %9.3f %8.2f  %s\n" % (i, cin, cout, k, s, ms_i, flops[i] * B / 1e9,
                                                                        flops[i] * B / (ms_i * 1e-3) / 1e12, kernels[i]))
 
+    h2d = None
+    if args.h2d:
+        host = images.cpu().pin_memory()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net.detect(host.to("cuda", non_blocking=True), 50, 0.5, 0.5)
+        barrier()
+        dth = time.perf_counter() - t0
+        h2d = {"images_per_sec": round(B * args.steps / dth, 2), "ms_per_step": round(dth / args.steps * 1e3, 4),
+               "what": "same step with the %d MB f32 batch copied from pinned host memory each step (serial copy + compute)"
+                       % (images.numel() * 4 // 1000000)}
+
     if rank == 0:
         res = {
             "metric": "YOLOv3-416 images/sec end-to-end (conv+decode+NMS)",
@@ -180,6 +195,8 @@ def main():
                        "global_batch": world * B, "detections_last_step": ndet, "parallelism": "image-sharded dp%d" % world},
             "roofline": roofline,
         }
+        if h2d is not None:
+            res["pcie_inclusive"] = h2d
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_images, min(16, os.cpu_count() or 1))
         print(json.dumps(res))

@@ -100,57 +100,78 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
             koff[m][j] = kq < 27 ? ky * IWP + (kq - ky * 9) : 0;      // k >= 27: any finite value (its weight is 0)
         }
 
-    auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
-        const int per_img = p.tiles_x * p.tiles_y;
-        b = tile / per_img;
-        const int r = tile - b * per_img;
-        const int ty = r / p.tiles_x;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const float inv_per_img = 1.0f / (float)per_img, inv_tx = 1.0f / (float)p.tiles_x;
+    auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {     // tile < 2^24: float quotient + fix-up
+        b = (int)((float)tile * inv_per_img);
+        int r = tile - b * per_img;
+        if (r < 0) { --b; r += per_img; } else if (r >= per_img) { ++b; r -= per_img; }
+        int ty = (int)((float)r * inv_tx);
+        int tx = r - ty * p.tiles_x;
+        if (tx < 0) { --ty; tx += p.tiles_x; } else if (tx >= p.tiles_x) { ++ty; tx -= p.tiles_x; }
         oy0 = ty * TH;
-        ox0 = (r - ty * p.tiles_x) * 16;
+        ox0 = tx * 16;
     };
+    // image patch element e of this thread: tile-invariant LDS index, offset from the patch origin and (row, pixel)
     float pre[NE];
-    auto load_image_patch = [&](int tile) {            // global -> registers; out-of-image elements read a clamped pixel
-        int b, oy0, ox0;
-        tile_origin(tile, b, oy0, ox0);
-        const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
+    int lidx[NE], goff[NE], ipos[NE];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int idx = tid + e * NT;
-            int iy = idx / IROW;
-            const int rx = idx - iy * IROW;
-            iy = iy < IH ? iy : IH - 1;
-            int gy = gy0 + iy, gx = gx0 + rx / 3;
-            gy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
-            gx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-            pre[e] = p.img[(((long long)b * p.H + gy) * p.W + gx) * 3 + rx % 3];
+    for (int e = 0; e < NE; ++e) {
+        const int idx = tid + e * NT;
+        const bool v = idx < IH * IROW;
+        const int iy = v ? idx / IROW : 0;
+        const int rx = v ? idx - iy * IROW : 0;
+        lidx[e] = v ? iy * IWP + rx : -1;
+        goff[e] = iy * p.W * 3 + rx;
+        ipos[e] = iy | ((rx / 3) << 8) | ((rx % 3) << 16);
+    }
+    auto load_image_patch = [&](int b, int oy0, int ox0) {      // global -> registers
+        const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
+        const bool interior = gy0 >= 0 && gy0 + IH <= p.H && gx0 >= 0 && gx0 + 35 <= p.W;      // wave-uniform
+        if (interior) {
+            const float* org = p.img + (((long long)b * p.H + gy0) * p.W + gx0) * 3;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) pre[e] = org[lidx[e] >= 0 ? goff[e] : 0];
+        } else {                                                  // out-of-image elements read a clamped pixel
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                int gy = gy0 + (ipos[e] & 255), gx = gx0 + ((ipos[e] >> 8) & 255);
+                gy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+                pre[e] = p.img[(((long long)b * p.H + gy) * p.W + gx) * 3 + (ipos[e] >> 16)];
+            }
         }
     };
-    auto store_image_patch = [&](int tile) {           // registers -> LDS, zeros outside the image (the stem's SAME padding)
-        int b, oy0, ox0;
-        tile_origin(tile, b, oy0, ox0);
+    auto store_image_patch = [&](int oy0, int ox0) {             // registers -> LDS, zeros outside the image (SAME padding)
         const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
+        const bool interior = gy0 >= 0 && gy0 + IH <= p.H && gx0 >= 0 && gx0 + 35 <= p.W;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int idx = tid + e * NT;
-            const int iy = idx / IROW, rx = idx - iy * IROW;
-            const int gy = gy0 + iy, gx = gx0 + rx / 3;
-            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            if (idx < IH * IROW) img[iy * IWP + rx] = inside ? pre[e] : 0.f;
+            bool inside = true;
+            if (!interior) {
+                const int gy = gy0 + (ipos[e] & 255), gx = gx0 + ((ipos[e] >> 8) & 255);
+                inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            }
+            if (lidx[e] >= 0) img[lidx[e]] = inside ? pre[e] : 0.f;
         }
     };
 
     int tile = blockIdx.x;
+    int nb = 0, noy0 = 0, nox0 = 0;                    // origin of the tile whose image patch is in flight / in LDS
     if (tile < p.ntiles) {
-        load_image_patch(tile);
-        store_image_patch(tile);
+        tile_origin(tile, nb, noy0, nox0);
+        load_image_patch(nb, noy0, nox0);
+        store_image_patch(noy0, nox0);
     }
     __syncthreads();
 
     for (; tile < p.ntiles; tile += gridDim.x) {
-        int b, oy0, ox0;
-        tile_origin(tile, b, oy0, ox0);
+        const int b = nb, oy0 = noy0, ox0 = nox0;
         const int next = tile + gridDim.x;
-        if (next < p.ntiles) load_image_patch(next);   // in flight during the two compute phases
+        if (next < p.ntiles) {
+            tile_origin(next, nb, noy0, nox0);
+            load_image_patch(nb, noy0, nox0);          // in flight during the two compute phases
+        }
 
         // ---- stem: groups of 32 stem pixels --------------------------------------------------------------
         for (int g = wave; g < NG; g += NW) {
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
         }
         __syncthreads();                               // staging complete; img and stem patch are free again
 
-        if (next < p.ntiles) store_image_patch(next);
+        if (next < p.ntiles) store_image_patch(noy0, nox0);
         // ---- stores: 8 x 16 B per pixel, pixels of a tile row contiguous in memory ----------------------------
 #pragma unroll
         for (int it = 0; it < (TH * 16 * 8) / NT; ++it) {

@@ -176,6 +176,55 @@ __global__ __launch_bounds__(256) void decode_compact_kernel(DecodeK k, float th
     }
 }
 
+// ---- 1c. the same for detection-style thresholds: box-level gate, no LDS tile ---------------------------------
+// score = conf * prob with prob <= 1, so a box whose conf = sigmoid(t4) is below the threshold cannot contribute a
+// candidate in ANY class (rounding to nearest is monotone: conf * prob <= conf).  One thread per box reads only the
+// five leading logits of its row, decodes and stores the box, and votes; the wave then walks its active boxes one
+// at a time, lanes = classes (coalesced row read), one atomic per candidate.  With a detector's usual threshold a
+// few per cent of the boxes are active: the class logits of all others are never read.  Keys are the ones
+// decode_compact_kernel produces (same expression), in a different order inside a (image, class) list, which the
+// selection kernel does not depend on.  The host picks this kernel for score_thresh >= 0.05.
+template <int MODE>
+__global__ __launch_bounds__(256) void decode_sparse_kernel(DecodeK k, float thr, int* __restrict__ cand_count,
+                                                            u64* __restrict__ cand_keys) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = j < k.n;
+    const int jc = valid ? j : k.n - 1;
+    const int s = (jc >= k.off[1]) + (jc >= k.off[2]);
+    const int local = jc - k.off[s];
+    const int ns = k.off[s + 1] - k.off[s];
+    const float* row = k.fm[s] + ((long long)b * ns + local) * k.A;
+    float t[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i] = row[i];
+    if (valid) {
+        f32x4 box;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) box[a] = decode_box_attr(k, s, local, t, a);         // model.py:76-108,147-152
+        ((f32x4*)k.boxes)[(long long)b * k.n + j] = box;
+    }
+    const float conf = sigmoid_fast(t[4]);                                                // model.py:134
+    u64 todo = __ballot(valid && conf >= thr);
+    const int C = k.C;
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float* rowl = (const float*)(((unsigned long long)(unsigned)__shfl((int)((unsigned long long)row >> 32), l) << 32) |
+                                           (unsigned)__shfl((int)(unsigned long long)row, l));
+        const float confl = __shfl(conf, l);
+        const unsigned jl = (unsigned)__shfl(j, l);
+        for (int c = lane; c < C; c += 64) {
+            const float sc = confl * sigmoid_fast(rowl[5 + c]);                           // model.py:135, test_single_image.py:38
+            if (sc >= thr) {                                                              // nms_utils.py:22
+                const int pos = atomicAdd(cand_count + (long long)b * C + c, 1);
+                cand_keys[((long long)b * C + c) * k.n + pos] = make_key<MODE>(sc, jl);
+            }
+        }
+    }
+}
+
 // ---- 2. selection ------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict__ boxes, int n, int C, int max_boxes,
@@ -397,7 +446,11 @@ static int post_run(DecodeK k, int B, int max_boxes, float st, float it, float* 
         if (dev < 16) attr_done[dev] = true;
     }
     k.boxes = w.boxes;
-    hipLaunchKernelGGL(fn, dim3(tiles, B), dim3(256), lds, stream, k, st, w.cand_count, w.cand_keys);
+    if (st >= 0.05f)      // box-level conf gate pays when few boxes pass; below, the dense tile kernel (1 atomic per 64 boxes)
+        hipLaunchKernelGGL(decode_sparse_kernel<YOLO_NMS_TF>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, stream, k, st,
+                           w.cand_count, w.cand_keys);
+    else
+        hipLaunchKernelGGL(fn, dim3(tiles, B), dim3(256), lds, stream, k, st, w.cand_count, w.cand_keys);
     YOLO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_select_kernel<YOLO_NMS_TF>, dim3((unsigned)(B * C)), dim3(256), 0, stream, w.boxes, n, C, max_boxes, it,
                        w.cand_count, w.cand_keys, w.sel_count, w.sel_idx, w.sel_score);
