@@ -25,7 +25,12 @@ F32_PEAK_TFLOPS = 157.3
 # HBM-side bytes per launch of a kernel instantiation, from the committed PMC passes (profiles/, see DESIGN.md
 # section 5): 2 x FETCH_SIZE + WRITE_SIZE averaged over the launches of one bench step (FETCH_SIZE doubled as
 # MI355X_MICROARCH.md "HBM" prescribes for gfx950).  Keyed by (kernel, batch, size); None when not measured.
-TRAFFIC_BYTES_PER_LAUNCH = {}
+TRAFFIC_BYTES_PER_LAUNCH = {
+    # profiles/r1_bench_pmc_traffic_v3.txt: fetch 138.26 MB (2 x FETCH_SIZE) + write 35.69 MB
+    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, false>", 64, 416): 173.95e6,
+    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, true>", 64, 416): 245.70e6,
+    ("yolo::conv_igemm_kernel<true, 128, 128, 4, 2, 2>", 64, 416): 119.90e6,
+}
 
 
 def conv_flops_per_image(info, H, W):
