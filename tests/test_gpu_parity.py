@@ -449,8 +449,9 @@ def test_detect_post_argument_errors(net_f32):
 
 
 def test_front_fusion_equals_separate_kernels(net_bf16):
-    """bf16: the fused stem + first stride-2 conv kernel (front.hip) gives the feature maps of the two separate
-    kernels bit for bit (same products, same accumulation order, same activation rounding)."""
+    """bf16: the fused stem + first stride-2 conv kernel (front.hip) and the fused first residual block
+    (resblock.hip) give the feature maps of the separate kernels bit for bit (same products, same accumulation
+    order, same roundings)."""
     import os
     import torch
     rng = np.random.default_rng(23)
@@ -458,9 +459,11 @@ def test_front_fusion_equals_separate_kernels(net_bf16):
         x = rng.random((B, H, W, 3), dtype=np.float32)
         fused = [f.clone() for f in net_bf16.forward(x)]
         os.environ["YOLO_NO_FRONT_FUSION"] = "1"
+        os.environ["YOLO_NO_RES_FUSION"] = "1"
         try:
             plain = [f.clone() for f in net_bf16.forward(x)]
         finally:
             del os.environ["YOLO_NO_FRONT_FUSION"]
+            del os.environ["YOLO_NO_RES_FUSION"]
         for a, b in zip(fused, plain):
             assert torch.equal(a, b), float((a - b).abs().max())

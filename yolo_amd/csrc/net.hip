@@ -516,8 +516,14 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
     const bool fuse_front = net->kind == 3 && net->dtype == YOLO_DTYPE_BF16 && !no_fusion && P->steps.size() > 2 &&
                             P->steps[0].layer == 0 && P->steps[1].layer == 1 && P->steps[1].in == P->steps[0].out &&
                             P->steps[1].res < 0;
-    ConvLaunch front_p;
+    // ... and the first residual block (1x1 64->32, 3x3 32->64, + shortcut) as ONE kernel (YOLO_NO_RES_FUSION=1: apart)
+    const char* nr_env = getenv("YOLO_NO_RES_FUSION");
+    const bool fuse_res = net->kind == 3 && net->dtype == YOLO_DTYPE_BF16 && !(nr_env && atoi(nr_env) != 0) &&
+                          P->steps.size() > 4 && P->steps[2].layer == 2 && P->steps[3].layer == 3 &&
+                          P->steps[3].in == P->steps[2].out && P->steps[3].res == P->steps[2].in && P->steps[2].res < 0;
+    ConvLaunch front_p, res_p;
     memset(&front_p, 0, sizeof(front_p));
+    memset(&res_p, 0, sizeof(res_p));
     for (const Step& st : P->steps) {
         if (st.layer < 0) {                       // pooling_layer (yolo_v2.py:91-94)
             const Tens& ti = P->tens[st.in];
@@ -549,6 +555,22 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
         if (events) YOLO_HIP_CHECK(hipEventRecord(events[st.layer], (hipStream_t)stream));
         if (fuse_front && st.layer == 0) {        // held back: launched together with layer 1 (front.hip)
             front_p = p;
+            continue;
+        }
+        if (fuse_res && st.layer == 2) {          // held back: launched together with layer 3 (resblock.hip)
+            res_p = p;
+            continue;
+        }
+        if (fuse_res && st.layer == 3) {
+            ConvLaunch p1 = res_p, p3 = p;
+            fill_conv(*net->layers[2], p1);
+            fill_conv(L, p3);
+            rc = launch_res_block(p1, p3, (hipStream_t)stream);
+            if (rc != YOLO_OK) return rc;
+            if (record_kernel_names) {
+                net->kernel_names[2] = "(fused into layer 3)";
+                net->kernel_names[3] = last_kernel_name();
+            }
             continue;
         }
         if (fuse_front && st.layer == 1) {
