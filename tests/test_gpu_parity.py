@@ -467,3 +467,45 @@ def test_front_fusion_equals_separate_kernels(net_bf16):
             del os.environ["YOLO_NO_RES_FUSION"]
         for a, b in zip(fused, plain):
             assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_lanes_equal_single_launch(net_bf16, net_f32):
+    """forward splits the batch into lanes (sub-batches on streams of their own, net.hip forward_lanes): the feature
+    maps are those of one launch per layer over the whole batch, bit for bit, also for uneven splits."""
+    import os
+    import torch
+    rng = np.random.default_rng(29)
+    for net, B, H, W in ((net_bf16, 13, 96, 96), (net_bf16, 5, 64, 32), (net_f32, 3, 32, 64)):
+        x = rng.random((B, H, W, 3), dtype=np.float32)
+        outs = {}
+        try:
+            for lanes in (1, 2, 3, 4):
+                os.environ["YOLO_LANES"] = str(lanes)
+                outs[lanes] = [f.clone() for f in net.forward(x)]
+        finally:
+            del os.environ["YOLO_LANES"]
+        outs[0] = [f.clone() for f in net.forward(x)]              # default lane count
+        for lanes in (0, 2, 3, 4):
+            for a, b in zip(outs[1], outs[lanes]):
+                assert torch.equal(a, b), (lanes, float((a - b).abs().max()))
+
+
+def test_lanes_workspace_checked(net_bf16):
+    """a workspace sized for fewer images than the call is refused, with lanes as without."""
+    import ctypes
+    import torch
+    from yolo_amd import _lib
+    L = _lib.lib()
+    B, H, W = 16, 64, 64
+    need = L.yolo_net_workspace_bytes(net_bf16._net, B, H, W)
+    assert need >= L.yolo_net_workspace_bytes(net_bf16._net, B // 2, H, W) * 2 - 4096
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    x = torch.zeros((B, H, W, 3), device="cuda")
+    fms = [torch.empty((B, H // r, W // r, 255), device="cuda") for r in (32, 16, 8)]
+    rc = L.yolo_net_forward(net_bf16._net, x.data_ptr(), B, H, W, ws.data_ptr(), need // 4, fms[0].data_ptr(),
+                            fms[1].data_ptr(), fms[2].data_ptr(), None)
+    assert rc == -5                                            # YOLO_ERR_WORKSPACE
+    rc = L.yolo_net_forward(net_bf16._net, x.data_ptr(), B, H, W, ws.data_ptr(), need, fms[0].data_ptr(),
+                            fms[1].data_ptr(), fms[2].data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()

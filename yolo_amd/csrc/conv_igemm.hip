@@ -15,6 +15,7 @@
 //   * double-buffered LDS, one barrier per 128-byte K-step.
 //   * epilogue through LDS so that stores are 16 B per lane, channel-contiguous.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace yolo {
@@ -70,21 +71,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
     float* ct = (float*)lds;
     __syncthreads();                      // every wave is done reading the staging buffers
     STAMP(5);
+    auto to_lds = [&](auto mode) {              // activation mode as a compile-time constant: no branch per element
+        constexpr int MODE = decltype(mode)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = wn0 + j * 32 + fr;
-        const float bv = p.bias[n0 + col];
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn0 + j * 32 + fr;
+            const float bv = p.bias[n0 + col];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = acc[i][j][r] + bv;
-                if (p.leaky == 1) v = leaky_v3(v);
-                else if (p.leaky == 2) v = __builtin_fmaxf(0.1f * v, v);
-                ct[row * LDC + col] = v;
-            }
-    }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    float v = acc[i][j][r] + bv;
+                    if constexpr (MODE == 1) v = leaky_v3(v);
+                    else if constexpr (MODE == 2) v = __builtin_fmaxf(0.1f * v, v);
+                    ct[row * LDC + col] = v;
+                }
+        }
+    };
+    if (p.leaky == 1) to_lds(std::integral_constant<int, 1>{});
+    else if (p.leaky == 2) to_lds(std::integral_constant<int, 2>{});
+    else to_lds(std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     STAMP(6);
     __syncthreads();

@@ -226,6 +226,15 @@ struct YoloNet {
     std::vector<std::unique_ptr<ConvParams>> layers;
     std::map<std::tuple<int, int, int>, Plan> plans;
     std::mutex mu;
+    // lanes (forward_lanes): side streams + fork/join events, created on first use on the device of that call
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> side_done;
+    hipEvent_t fork_ev = nullptr;
+    ~YoloNet() {
+        for (hipStream_t s : side) (void)hipStreamDestroy(s);
+        for (hipEvent_t e : side_done) (void)hipEventDestroy(e);
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
+    }
 };
 struct YoloConv { ConvParams p; };
 
@@ -428,8 +437,8 @@ extern "C" int yolo_net_create(int class_num, int dtype, const float* stream, si
     return YOLO_OK;
 }
 
-static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
-                        float* fm1, float* fm2, float* fm3, void* stream, hipEvent_t* events);
+static int forward_lanes(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                         float* fm1, float* fm2, float* fm3, void* stream);
 
 // YOLOv2 weights: the reference keeps them in a TF checkpoint; this entry takes the variables concatenated in
 // creation order per conv (yolo_v2.py:75-83): weight [k,k,cin,cout] (HWIO), biases, then for batch-norm layers
@@ -480,7 +489,7 @@ extern "C" int yolo2_net_create(int num_class, int box_per_cell, int dtype, cons
 extern "C" int yolo2_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
                                  size_t workspace_bytes, float* logits, void* stream) {
     YOLO_REQUIRE(net && net->kind == 2, YOLO_ERR_ARG, "yolo2_net_forward: not a YOLOv2 handle");
-    return forward_impl(net, images, B, H, W, workspace, workspace_bytes, logits, nullptr, nullptr, stream, nullptr);
+    return forward_lanes(net, images, B, H, W, workspace, workspace_bytes, logits, nullptr, nullptr, stream);
 }
 
 extern "C" int yolo_net_destroy(YoloNet* net) {
@@ -490,11 +499,38 @@ extern "C" int yolo_net_destroy(YoloNet* net) {
 
 extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->layers.size() : 0; }
 
+// ---- lanes ------------------------------------------------------------------------------------------
+// Images are independent, so a batch runs as up to MAX_LANES sub-batches, each the whole layer chain on a stream of
+// its own (lane 0 on the caller's stream, forked / joined with events).  Kernels of different lanes overlap on the
+// GPU: the partly filled last round of workgroups of one launch (e.g. 676 tiles on 512 slots) and the drain / fill
+// between dependent launches are covered by the other lane's kernels.  Results do not depend on the split: every
+// output element is accumulated in the same order whatever tile or batch it is part of.
+// Default: 2 lanes from batch 12 up.  YOLO_LANES=<n> in the environment (read per call) sets the number of lanes;
+// 1 = one launch per layer for the whole batch.
+constexpr int MAX_LANES = 4;
+static int lane_count(int B) {
+    const char* e = getenv("YOLO_LANES");
+    int n = e ? atoi(e) : (B >= 12 ? 2 : 1);      // measured (scripts/lanes.py): +5..8 % from batch 12 up, a loss below 8
+    if (n < 1) n = 1;
+    if (n > MAX_LANES) n = MAX_LANES;
+    return n < B ? n : B;
+}
+static int lane_batch(int B, int lanes, int i) { return B / lanes + (i < B % lanes ? 1 : 0); }
+
 extern "C" size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int W) {
     if (!net) return 0;
     const Plan* P = nullptr;
     if (get_plan(const_cast<YoloNet*>(net), B, H, W, &P) != YOLO_OK) return 0;
-    return P->ws_bytes;
+    size_t need = P->ws_bytes;                      // the unsplit plan always fits (YOLO_LANES=1, forward_timed)
+    for (int lanes = 2; lanes <= MAX_LANES && lanes <= B; ++lanes) {
+        size_t sum = 0;
+        for (int i = 0; i < lanes; ++i) {
+            if (get_plan(const_cast<YoloNet*>(net), lane_batch(B, lanes, i), H, W, &P) != YOLO_OK) return 0;
+            sum += align_up(P->ws_bytes, 256);
+        }
+        if (sum > need) need = sum;
+    }
+    return need;
 }
 
 static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
@@ -590,10 +626,65 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
     return YOLO_OK;
 }
 
+static int forward_lanes(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                         float* fm1, float* fm2, float* fm3, void* stream) {
+    YOLO_REQUIRE(net && B > 0, YOLO_ERR_ARG, "forward: bad handle or batch");
+    const int lanes = lane_count(B);
+    if (lanes == 1) return forward_impl(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream, nullptr);
+    YOLO_REQUIRE(images && workspace && fm1 && (net->kind == 2 || (fm2 && fm3)), YOLO_ERR_ARG, "forward: null pointer");
+    YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "forward: workspace must be 256-byte aligned");
+    YOLO_REQUIRE(H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, YOLO_ERR_SHAPE, "forward: H, W must be multiples of 32 (got %dx%d)", H, W);
+    size_t ws_off[MAX_LANES + 1] = {0};
+    for (int i = 0; i < lanes; ++i) {
+        const Plan* P = nullptr;
+        int rc = get_plan(net, lane_batch(B, lanes, i), H, W, &P);
+        if (rc != YOLO_OK) return rc;
+        ws_off[i + 1] = ws_off[i] + align_up(P->ws_bytes, 256);
+    }
+    YOLO_REQUIRE(workspace_bytes >= ws_off[lanes], YOLO_ERR_WORKSPACE, "forward: workspace %zu < %zu bytes", workspace_bytes, ws_off[lanes]);
+    {
+        std::lock_guard<std::mutex> g(net->mu);
+        if (!net->fork_ev) YOLO_HIP_CHECK(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+        while ((int)net->side.size() < lanes - 1) {
+            hipStream_t s;
+            hipEvent_t e;
+            YOLO_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            net->side.push_back(s);
+            YOLO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            net->side_done.push_back(e);
+        }
+    }
+    const int nout = (net->kind == 2 ? net->box_per_cell : 3) * (5 + net->class_num);
+    const hipStream_t main_s = (hipStream_t)stream;
+    YOLO_HIP_CHECK(hipEventRecord(net->fork_ev, main_s));
+    int rc = YOLO_OK, b0 = 0, forked = 0;
+    for (int i = 0; i < lanes && rc == YOLO_OK; ++i) {
+        const int Bi = lane_batch(B, lanes, i);
+        const hipStream_t s = i == 0 ? main_s : net->side[i - 1];
+        if (i > 0) {
+            if (hipStreamWaitEvent(s, net->fork_ev, 0) != hipSuccess) { set_error("forward: fork failed"); rc = YOLO_ERR_HIP; break; }
+            forked = i;
+        }
+        const size_t px1 = (size_t)(H / 32) * (W / 32) * nout;
+        rc = forward_impl(net, images + (size_t)b0 * H * W * 3, Bi, H, W, (char*)workspace + ws_off[i], ws_off[i + 1] - ws_off[i],
+                          fm1 + (size_t)b0 * px1, fm2 ? fm2 + (size_t)b0 * px1 * 4 : nullptr, fm3 ? fm3 + (size_t)b0 * px1 * 16 : nullptr,
+                          s, nullptr);
+        b0 += Bi;
+    }
+    // join every lane that was forked, also after an error, so that the caller's stream orders after all launched work
+    for (int i = 1; i <= forked; ++i) {
+        if (hipEventRecord(net->side_done[i - 1], net->side[i - 1]) != hipSuccess ||
+            hipStreamWaitEvent(main_s, net->side_done[i - 1], 0) != hipSuccess) {
+            if (rc == YOLO_OK) { set_error("forward: join failed"); rc = YOLO_ERR_HIP; }
+        }
+    }
+    return rc;
+}
+
 extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
                                 float* fm1, float* fm2, float* fm3, void* stream) {
     YOLO_REQUIRE(net && net->kind == 3, YOLO_ERR_ARG, "yolo_net_forward: not a YOLOv3 handle");
-    return forward_impl(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream, nullptr);
+    return forward_lanes(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream);
 }
 
 // Measurement aid: one forward with a hipEvent before every layer's launch (on `stream`), then a stream
