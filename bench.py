@@ -176,16 +176,28 @@ def main():
 
     h2d = None
     if args.h2d:
+        from yolo_amd.preprocess import preprocess
         host = images.cpu().pin_memory()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = net.detect(host.to("cuda", non_blocking=True), 50, 0.5, 0.5)
-        barrier()
-        dth = time.perf_counter() - t0
-        h2d = {"images_per_sec": round(B * args.steps / dth, 2), "ms_per_step": round(dth / args.steps * 1e3, 4),
+        host_u8 = torch.from_numpy(rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)).pin_memory()
+
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            barrier()
+            return (time.perf_counter() - t0) / args.steps
+
+        dth = timed(lambda: net.detect(host.to("cuda", non_blocking=True), 50, 0.5, 0.5))
+        dtu = timed(lambda: net.detect(preprocess(host_u8.to("cuda", non_blocking=True), (S, S)), 50, 0.5, 0.5))
+        h2d = {"images_per_sec": round(B / dth, 2), "ms_per_step": round(dth * 1e3, 4),
                "what": "same step with the %d MB f32 batch copied from pinned host memory each step (serial copy + compute)"
-                       % (images.numel() * 4 // 1000000)}
+                       % (images.numel() * 4 // 1000000),
+               "uint8_upload": {"images_per_sec": round(B / dtu, 2), "ms_per_step": round(dtu * 1e3, 4),
+                                "what": "%d MB uint8 BGR batch copied from pinned host memory, then yolo_preprocess "
+                                        "(resize / BGR2RGB / /255 on the GPU) + the step" % (host_u8.numel() // 1000000)}}
 
     if rank == 0:
         res = {

@@ -133,6 +133,16 @@ int yolo_detect_post(const float* fm1, const float* fm2, const float* fm3, int B
                      float* out_scores, int32_t* out_labels, int32_t* out_index, int32_t* out_counts,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- image preprocessing: replaces the host-side steps before the network,
+ * cv2.resize(img, new_size) [INTER_LINEAR, 8-bit fixed point] -> cv2.cvtColor(BGR2RGB) -> float32(img) / 255.
+ * (yolo_v3/test_single_image.py:25-28, yolo_v3/video_test.py:61-64); mode 1 ends in `/ 255.0 * 2.0 - 1.0`
+ * (yolo_v2/Detector.py:37-39).  images: DEVICE uint8 [B, src_h, src_w, 3] in BGR, rows src_row_bytes apart
+ * (0: packed), images src_row_bytes * src_h apart; out: DEVICE float32 [B, H, W, 3] RGB = the `inputs` of
+ * yolo_net_forward / yolo2_net_forward.  OpenCV is an un-vendored dependency of the reference and not installed:
+ * the filter restates its algorithm (see preprocess.hip), parity with cv2 itself is unpinned. */
+int yolo_preprocess(const uint8_t* images, int B, int src_h, int src_w, int src_row_bytes, float* out, int H, int W,
+                    int mode, void* stream);
+
 /* ---- YOLOv2 (config 4).  yolo2_net_create/forward replace yolo_v2.build_networks + conv_layer + pooling_layer +
  * reorg (yolo_v2/yolo/yolo_v2.py:32-113).  vars: HOST float32, the TF variables concatenated in creation order per
  * conv (yolo_v2.py:75-83): weight [k,k,cin,cout], biases, then (batch-norm layers) scale, shift, rolling_mean,

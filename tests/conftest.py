@@ -15,6 +15,13 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import yolo_oracle
     return yolo_oracle

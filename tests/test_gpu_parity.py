@@ -14,13 +14,6 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
-    return torch
-
-
-@pytest.fixture(scope="module")
 def net_f32(torch_cuda, oracle, weight_stream):
     from yolo_amd.model import yolov3
     return yolov3(80, oracle.YOLO_ANCHORS, dtype="fp32").load_weight_stream(weight_stream)

@@ -220,3 +220,21 @@ def test_detect_batch64_properties(v2_bf16, O2):
         np.testing.assert_array_equal(flat[b, :m].cpu().numpy(), rf)
         p = op[b, :m].cpu().numpy()
         assert np.all(p[:-1] >= p[1:]) and np.all(p >= np.float32(0.3))
+
+
+def test_detect_resizes_uint8_images_on_gpu(detector, v2_f32):
+    """Detector.detect on a uint8 BGR image of another size = the reference's resize / BGR2RGB / normalise lines
+    (Detector.py:37-39, restated by the preprocessing oracle) followed by the network, calc_output and the rescale."""
+    from oracle import preprocess_oracle as P
+    rng = np.random.default_rng(41)
+    img = rng.integers(0, 256, (300, 500, 3), dtype=np.uint8)
+    got = detector.detect(img)
+    x = P.preprocess(img, (416, 416), v2=True)
+    ref = detector.calc_output(v2_f32.build_networks(x))
+    assert isinstance(got, list) and len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert g[0] == r[0] and g[5] == r[5]
+        assert g[1] == r[1] * (1.0 * 500 / 416) and g[2] == r[2] * (1.0 * 300 / 416)
+        assert g[3] == r[3] * (1.0 * 500 / 416) and g[4] == r[4] * (1.0 * 300 / 416)
+    with pytest.raises(ValueError):
+        detector.detect(np.zeros((300, 500, 3), np.float32))

@@ -59,8 +59,10 @@ struct ConvK {
 // All residual loads of a thread are issued before the first one is consumed.
 // (A register-direct epilogue with the MFMA operands swapped - 4 consecutive channels per lane, 8-byte
 // stores, no LDS - was measured 15-25 % SLOWER per layer: 32 partial lines per store instruction.)
-template <bool BF16, int BM, int BN, int TM, int TN, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], char* lds, int m0, int n0,
+// MS: MFMA tile edge (32: v_mfma_f32_32x32x16_bf16 / 32x32x2_f32, 16 registers per lane; 16: v_mfma_f32_16x16x32_bf16,
+// 4 registers per lane).  fr = lane % MS (column), fh = lane / MS; register r holds row (r&3) + 8*(r>>2) + 4*fh.
+template <bool BF16, int BM, int BN, int TM, int TN, int NT, int MS = 32, typename AccT = f32x16>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN], char* lds, int m0, int n0,
                                               int wm0, int wn0, int tid, int fr, int fh
 #ifdef YOLO_CONV_STAMPS
                                               , unsigned long long (&st_)[8], unsigned long long& tl_
@@ -75,13 +77,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
         constexpr int MODE = decltype(mode)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = wn0 + j * 32 + fr;
+            const int col = wn0 + j * MS + fr;
             const float bv = p.bias[n0 + col];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                for (int r = 0; r < MS * MS / 64; ++r) {
+                    const int row = wm0 + i * MS + (r & 3) + 8 * (r >> 2) + 4 * fh;
                     float v = acc[i][j][r] + bv;
                     if constexpr (MODE == 1) v = leaky_v3(v);
                     else if constexpr (MODE == 2) v = __builtin_fmaxf(0.1f * v, v);
@@ -419,13 +421,19 @@ extern "C" int yolo_debug_read_stamps(unsigned long long* host, int n) {
 // K order of the packed weights stays (ky,kx,ci); the loop order here is (ci-chunk, tap).
 // SPB (single patch buffer): the patch of the next channel chunk is loaded only after the last tap of the current
 // one (one exposed load latency per chunk) - half the patch LDS, so that two workgroups fit a CU at larger W.
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB>
+// MS = 16 (bf16 only): the same wave tile out of v_mfma_f32_16x16x32_bf16 - same LDS reads and MFMA cycles per FLOP;
+// the chip holds a higher clock on that shape (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB, int MS>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(ConvK p, int prows) {
+    static_assert(MS == 32 || (MS == 16 && BF16), "MFMA shape");
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int NT = 64 * NW;
-    constexpr int TM = BM / WARPS_M / 32;
-    constexpr int TN = BN / WARPS_N / 32;
+    constexpr int TM = BM / WARPS_M / MS;
+    constexpr int TN = BN / WARPS_N / MS;
+    constexpr int KK = MS / 8;                    // MFMA k-slices per 128-byte chunk: 4 x 32 B or 2 x 64 B
+    constexpr int KSH = MS == 32 ? 5 : 6;
+    typedef typename std::conditional<MS == 32, f32x16, f32x4>::type AccT;
     constexpr int B_BYTES = BN * 128;
     constexpr int BI = BN / 8 / NW;
     static_assert(BN % (8 * NW) == 0 && NW % 2 == 0 && BI >= 1, "loader geometry");
@@ -491,12 +499,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
 
     // ---- fragment addressing -----------------------------------------------------------------------
     const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
-    const int wm0 = wm * (TM * 32), wn0 = wn * (TN * 32);
-    const int fr = lane & 31, fh = lane >> 5;
+    const int wm0 = wm * (TM * MS), wn0 = wn * (TN * MS);
+    const int fr = lane & (MS - 1), fh = lane / MS;
     unsigned a_mask[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        const int m = m0 + wm0 + t * 32 + fr;
+        const int m = m0 + wm0 + t * MS + fr;
         unsigned mask = 0;
         if (m < p.M) {
             const int r = m % (p.H * W);
@@ -512,18 +520,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
     int b_row_off[TN], b_sx[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-        const int row = wn0 + t * 32 + fr;
+        const int row = wn0 + t * MS + fr;
         b_row_off[t] = row * 128;
         b_sx[t] = (((row >> 1) & 7) ^ fh) << 4;
     }
 
-    f32x16 acc[TM][TN];
+    AccT acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < MS * MS / 64; ++r) acc[i][j][r] = 0.f;
 
 #ifdef YOLO_CONV_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -562,28 +570,31 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
             const int ky = (t * 11) >> 5, kx = t - ky * 3;
             const int shift = ky * W + kx;
             const char* bbase = bbuf0 + bcur * B_BYTES;
-            u32x4 af[4][TM], bf[4][TN];
+            u32x4 af[KK][TM], bf[KK][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int prow = wm0 + i * 32 + fr + shift;
+                const int prow = wm0 + i * MS + fr + shift;
                 const bool ok = (a_mask[i] >> t) & 1;
                 const char* rowp = ok ? patch + prow * 128 : zrow;     // masked tap: read zeros
                 const int sx = (((prow >> 1) & 7) ^ fh) << 4;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) af[kk][i] = *(const u32x4*)(rowp + ((kk << 5) ^ sx));
+                for (int kk = 0; kk < KK; ++kk) af[kk][i] = *(const u32x4*)(rowp + ((kk << KSH) ^ sx));
             }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[kk][j] = *(const u32x4*)(bbase + b_row_off[j] + ((kk << 5) ^ b_sx[j]));
+                    bf[kk][j] = *(const u32x4*)(bbase + b_row_off[j] + ((kk << KSH) ^ b_sx[j]));
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if constexpr (BF16) {
+                        if constexpr (MS == 16) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
+                        } else if constexpr (BF16) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
                         } else {
@@ -603,9 +614,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
         }
     }
     #ifdef YOLO_CONV_STAMPS
-    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
+    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
 #else
-    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
+    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
 #endif
 #ifdef YOLO_CONV_STAMPS
     {
@@ -620,8 +631,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
 #endif
 }
 
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false>
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32>
 static int launch_halo(const ConvK& k, hipStream_t stream) {
+    if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32>(k, stream);
+    else {
     const int prows = (int)align_up((size_t)(BM + 2 * k.W + 2), 8);
     const int nchunks = k.Cin * (BF16 ? 2 : 4) / 128;
     const int loop_bytes = ((nchunks > 1 && !SPB) ? 2 : 1) * prows * 128 + 2 * BN * 128 + 128;
@@ -629,7 +642,7 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     const int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
     YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 halo: W=%d needs %d bytes of LDS", k.W, lds_bytes);
     YOLO_REQUIRE((long long)k.M * k.in_ld * (BF16 ? 2 : 4) < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 halo: input larger than 4 GiB");
-    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB>;
+    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB, MS>;
     static bool attr_done[16] = {false};
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
@@ -640,10 +653,11 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false");
+    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS);
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
+    }
 }
 
 template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES>
@@ -709,6 +723,8 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 26: return launch_halo<BF16, 256, 128, 8, 2>(k, stream);      // 16 waves, 1 block/CU
         case 27: return launch_halo<BF16, 256, 128, 4, 4>(k, stream);
         case 28: return launch_halo<BF16, 128, 128, 4, 2, true>(k, stream);   // single patch buffer: 2 blocks/CU up to W ~ 60
+        case 34: return launch_halo<BF16, 128, 128, 4, 2, false, 16>(k, stream);   // 24 / 28 out of 16x16x32 MFMAs
+        case 38: return launch_halo<BF16, 128, 128, 4, 2, true, 16>(k, stream);
         case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);

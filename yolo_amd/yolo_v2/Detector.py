@@ -2,9 +2,9 @@
 """`Detector` with the interface of reference yolo_v2/Detector.py:14-115, executed by libyolo_hip.so.
 
 `calc_output` (sigmoid / exp / softmax decode, threshold, class-agnostic greedy NMS) runs as two HIP
-kernels (yolo2_decode, yolo2_nms) instead of numpy + a Python double loop.  Image file I/O, cv2 resizing
-and drawing (detect's cv2 calls, draw, image_detect, video_detect) are outside the hot path: `detect`
-takes an image that already has the network's size.
+kernels (yolo2_decode, yolo2_nms) instead of numpy + a Python double loop.  Image file I/O
+and drawing (cv2.imread, draw, image_detect, video_detect) are outside the hot path; the cv2.resize / cvtColor /
+normalisation of `detect` (Detector.py:37-39) run as one GPU kernel (yolo_preprocess) for uint8 images.
 """
 import numpy as np
 import torch
@@ -34,16 +34,21 @@ class Detector(object):
 
     # ---- Detector.py:31-49 ------------------------------------------------------------------------
     def detect(self, image):
-        """image: uint8/float [image_size, image_size, 3] in BGR, values 0..255 -> list of
+        """image: uint8 [h, w, 3] in BGR as cv2.imread returns it (any size: resized on the GPU, yolo_preprocess), or
+        a float array [image_size, image_size, 3] in BGR with values 0..255 -> list of
         [class_name, x_center, y_center, w, h, prob] in the image's own pixels."""
         image = np.asarray(image)
         image_h, image_w, _ = image.shape
-        if image_h != self.image_size or image_w != self.image_size:
-            raise ValueError("detect: resize the image to %dx%d first (cv2.resize of Detector.py:37 is outside "
-                             "this build)" % (self.image_size, self.image_size))
-        image = image[:, :, ::-1].astype(np.float32)                    # BGR -> RGB (:38)
-        image = image / 255.0 * 2.0 - 1.0                               # :39
-        image = np.reshape(image, [1, self.image_size, self.image_size, 3])
+        if image.dtype == np.uint8:
+            from ..preprocess import preprocess
+            image = preprocess(image, (self.image_size, self.image_size), v2=True)         # :37-40
+        else:
+            if image_h != self.image_size or image_w != self.image_size:
+                raise ValueError("detect: float images must already be %dx%d (pass uint8 to have them resized)"
+                                 % (self.image_size, self.image_size))
+            image = image[:, :, ::-1].astype(np.float32)                    # BGR -> RGB (:38)
+            image = image / 255.0 * 2.0 - 1.0                               # :39
+            image = np.reshape(image, [1, self.image_size, self.image_size, 3])
         output = self.yolo.build_networks(image)                        # :41
         results = self.calc_output(output)
         sx, sy = 1.0 * image_w / self.image_size, 1.0 * image_h / self.image_size
