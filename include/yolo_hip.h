@@ -133,6 +133,15 @@ int yolo_detect_post(const float* fm1, const float* fm2, const float* fm3, int B
                      float* out_scores, int32_t* out_labels, int32_t* out_index, int32_t* out_counts,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* The whole hot chain of yolo_v3/test_single_image.py:31-40 for a batch as ONE call: yolov3.forward -> predict ->
+ * pred_confs * pred_probs -> gpu_nms, = yolo_net_forward followed by yolo_detect_post (same results, bit for bit);
+ * the feature maps live in the workspace, and with lanes (see yolo_net_forward) each lane's post-processing runs
+ * behind its own convs, overlapping the other lane.  anchors: HOST float32 [9][2]; outputs as yolo_detect_post. */
+size_t yolo_net_detect_workspace_bytes(const YoloNet* net, int B, int H, int W, int max_boxes);
+int yolo_net_detect(YoloNet* net, const float* images, int B, int H, int W, const float* anchors, int max_boxes,
+                    float score_thresh, float iou_thresh, float* out_boxes, float* out_scores, int32_t* out_labels,
+                    int32_t* out_index, int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- image preprocessing: replaces the host-side steps before the network,
  * cv2.resize(img, new_size) [INTER_LINEAR, 8-bit fixed point] -> cv2.cvtColor(BGR2RGB) -> float32(img) / 255.
  * (yolo_v3/test_single_image.py:25-28, yolo_v3/video_test.py:61-64); mode 1 ends in `/ 255.0 * 2.0 - 1.0`

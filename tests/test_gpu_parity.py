@@ -502,3 +502,32 @@ def test_lanes_workspace_checked(net_bf16):
                             fms[1].data_ptr(), fms[2].data_ptr(), None)
     assert rc == 0
     torch.cuda.synchronize()
+
+
+def test_detect_one_call_equals_forward_then_postprocess(net_bf16, net_f32):
+    """yolo_net_detect (forward + post-processing per lane in one call) = yolo_net_forward, then yolo_detect_post."""
+    import os
+    import torch
+    rng = np.random.default_rng(31)
+    for net, B, H, W, st in ((net_bf16, 13, 96, 96, 0.01), (net_f32, 3, 64, 96, 0.02), (net_bf16, 2, 416, 416, 0.3)):
+        x = rng.random((B, H, W, 3), dtype=np.float32)
+        ref = [t.clone() for t in net.postprocess(net.forward(x), 20, st, 0.45)]
+        outs = []
+        try:
+            for lanes in ("1", "3"):
+                os.environ["YOLO_LANES"] = lanes
+                outs.append([t.clone() for t in net.detect(x, 20, st, 0.45)])
+        finally:
+            del os.environ["YOLO_LANES"]
+        outs.append([t.clone() for t in net.detect(x, 20, st, 0.45)])
+        cnt = ref[4].cpu().numpy()
+        assert cnt.sum() > 0
+        for got in outs:
+            assert torch.equal(got[4], ref[4])
+            for b in range(B):
+                for k in range(4):
+                    assert torch.equal(got[k][b, :cnt[b]], ref[k][b, :cnt[b]]), (b, k)
+    with pytest.raises(ValueError):
+        net_f32.detect(np.zeros((1, 40, 64, 3), np.float32))
+    with pytest.raises(ValueError):
+        net_f32.detect(np.zeros((1, 64, 64, 3), np.float32), max_boxes=0)

@@ -41,6 +41,8 @@ SIGNATURES = {
     "yolo2_decode": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "yolo2_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "yolo2_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _c.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "yolo_net_detect_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "yolo_net_detect": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "yolo_preprocess": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "yolo_detect_post_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "yolo_detect_post": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

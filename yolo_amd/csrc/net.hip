@@ -626,6 +626,45 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
     return YOLO_OK;
 }
 
+// Runs lane_fn(lane, first image, images, stream) for every lane: lane 0 on the caller's stream, the others on the
+// handle's side streams, forked from / joined into the caller's stream with events.
+template <class F>
+static int run_lanes(YoloNet* net, int lanes, int B, hipStream_t main_s, F&& lane_fn) {
+    if (lanes == 1) return lane_fn(0, 0, B, main_s);
+    {
+        std::lock_guard<std::mutex> g(net->mu);
+        if (!net->fork_ev) YOLO_HIP_CHECK(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+        while ((int)net->side.size() < lanes - 1) {
+            hipStream_t s;
+            hipEvent_t e;
+            YOLO_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            net->side.push_back(s);
+            YOLO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            net->side_done.push_back(e);
+        }
+    }
+    YOLO_HIP_CHECK(hipEventRecord(net->fork_ev, main_s));
+    int rc = YOLO_OK, b0 = 0, forked = 0;
+    for (int i = 0; i < lanes && rc == YOLO_OK; ++i) {
+        const int Bi = lane_batch(B, lanes, i);
+        const hipStream_t s = i == 0 ? main_s : net->side[i - 1];
+        if (i > 0) {
+            if (hipStreamWaitEvent(s, net->fork_ev, 0) != hipSuccess) { set_error("forward: fork failed"); rc = YOLO_ERR_HIP; break; }
+            forked = i;
+        }
+        rc = lane_fn(i, b0, Bi, s);
+        b0 += Bi;
+    }
+    // join every lane that was forked, also after an error, so that the caller's stream orders after all launched work
+    for (int i = 1; i <= forked; ++i) {
+        if (hipEventRecord(net->side_done[i - 1], net->side[i - 1]) != hipSuccess ||
+            hipStreamWaitEvent(main_s, net->side_done[i - 1], 0) != hipSuccess) {
+            if (rc == YOLO_OK) { set_error("forward: join failed"); rc = YOLO_ERR_HIP; }
+        }
+    }
+    return rc;
+}
+
 static int forward_lanes(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
                          float* fm1, float* fm2, float* fm3, void* stream) {
     YOLO_REQUIRE(net && B > 0, YOLO_ERR_ARG, "forward: bad handle or batch");
@@ -642,43 +681,82 @@ static int forward_lanes(YoloNet* net, const float* images, int B, int H, int W,
         ws_off[i + 1] = ws_off[i] + align_up(P->ws_bytes, 256);
     }
     YOLO_REQUIRE(workspace_bytes >= ws_off[lanes], YOLO_ERR_WORKSPACE, "forward: workspace %zu < %zu bytes", workspace_bytes, ws_off[lanes]);
-    {
-        std::lock_guard<std::mutex> g(net->mu);
-        if (!net->fork_ev) YOLO_HIP_CHECK(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
-        while ((int)net->side.size() < lanes - 1) {
-            hipStream_t s;
-            hipEvent_t e;
-            YOLO_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            net->side.push_back(s);
-            YOLO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            net->side_done.push_back(e);
-        }
-    }
     const int nout = (net->kind == 2 ? net->box_per_cell : 3) * (5 + net->class_num);
-    const hipStream_t main_s = (hipStream_t)stream;
-    YOLO_HIP_CHECK(hipEventRecord(net->fork_ev, main_s));
-    int rc = YOLO_OK, b0 = 0, forked = 0;
-    for (int i = 0; i < lanes && rc == YOLO_OK; ++i) {
-        const int Bi = lane_batch(B, lanes, i);
-        const hipStream_t s = i == 0 ? main_s : net->side[i - 1];
-        if (i > 0) {
-            if (hipStreamWaitEvent(s, net->fork_ev, 0) != hipSuccess) { set_error("forward: fork failed"); rc = YOLO_ERR_HIP; break; }
-            forked = i;
+    const size_t px1 = (size_t)(H / 32) * (W / 32) * nout;
+    return run_lanes(net, lanes, B, (hipStream_t)stream, [&](int i, int b0, int Bi, hipStream_t s) {
+        return forward_impl(net, images + (size_t)b0 * H * W * 3, Bi, H, W, (char*)workspace + ws_off[i], ws_off[i + 1] - ws_off[i],
+                            fm1 + (size_t)b0 * px1, fm2 ? fm2 + (size_t)b0 * px1 * 4 : nullptr, fm3 ? fm3 + (size_t)b0 * px1 * 16 : nullptr,
+                            s, nullptr);
+    });
+}
+
+// ---- the whole chain in one call: forward -> predict -> conf*prob -> per-class NMS (test_single_image.py:31-40) ----------
+// Per lane: [forward workspace | fm1 | fm2 | fm3 | yolo_detect_post workspace]; the post-processing of a lane runs on the
+// lane's stream right behind its last conv, so it overlaps the other lane's convs.
+struct DetectLayout { size_t fwd, fm[3], post, total; };
+static int detect_layout(YoloNet* net, int Bi, int H, int W, int max_boxes, DetectLayout* d) {
+    const Plan* P = nullptr;
+    int rc = get_plan(net, Bi, H, W, &P);
+    if (rc != YOLO_OK) return rc;
+    const size_t px1 = (size_t)(H / 32) * (W / 32) * 3 * (5 + net->class_num) * sizeof(float);
+    const size_t post = yolo_detect_post_workspace_bytes(Bi, H, W, net->class_num, max_boxes);
+    YOLO_REQUIRE(post > 0, YOLO_ERR_ARG, "detect: bad sizes B=%d H=%d W=%d max_boxes=%d", Bi, H, W, max_boxes);
+    size_t off = 0;
+    d->fwd = off; off = align_up(off + P->ws_bytes, 256);
+    d->fm[0] = off; off = align_up(off + (size_t)Bi * px1, 256);
+    d->fm[1] = off; off = align_up(off + (size_t)Bi * px1 * 4, 256);
+    d->fm[2] = off; off = align_up(off + (size_t)Bi * px1 * 16, 256);
+    d->post = off; off = align_up(off + post, 256);
+    d->total = off;
+    return YOLO_OK;
+}
+
+extern "C" size_t yolo_net_detect_workspace_bytes(const YoloNet* net, int B, int H, int W, int max_boxes) {
+    if (!net || net->kind != 3 || B <= 0 || max_boxes <= 0) return 0;
+    size_t need = 0;
+    for (int lanes = 1; lanes <= MAX_LANES && lanes <= B; ++lanes) {
+        size_t sum = 0;
+        for (int i = 0; i < lanes; ++i) {
+            DetectLayout d;
+            if (detect_layout(const_cast<YoloNet*>(net), lane_batch(B, lanes, i), H, W, max_boxes, &d) != YOLO_OK) return 0;
+            sum += d.total;
         }
-        const size_t px1 = (size_t)(H / 32) * (W / 32) * nout;
-        rc = forward_impl(net, images + (size_t)b0 * H * W * 3, Bi, H, W, (char*)workspace + ws_off[i], ws_off[i + 1] - ws_off[i],
-                          fm1 + (size_t)b0 * px1, fm2 ? fm2 + (size_t)b0 * px1 * 4 : nullptr, fm3 ? fm3 + (size_t)b0 * px1 * 16 : nullptr,
-                          s, nullptr);
-        b0 += Bi;
+        if (sum > need) need = sum;
     }
-    // join every lane that was forked, also after an error, so that the caller's stream orders after all launched work
-    for (int i = 1; i <= forked; ++i) {
-        if (hipEventRecord(net->side_done[i - 1], net->side[i - 1]) != hipSuccess ||
-            hipStreamWaitEvent(main_s, net->side_done[i - 1], 0) != hipSuccess) {
-            if (rc == YOLO_OK) { set_error("forward: join failed"); rc = YOLO_ERR_HIP; }
-        }
+    return need;
+}
+
+extern "C" int yolo_net_detect(YoloNet* net, const float* images, int B, int H, int W, const float* anchors, int max_boxes,
+                               float score_thresh, float iou_thresh, float* out_boxes, float* out_scores, int32_t* out_labels,
+                               int32_t* out_index, int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream) {
+    YOLO_REQUIRE(net && net->kind == 3, YOLO_ERR_ARG, "yolo_net_detect: not a YOLOv3 handle");
+    YOLO_REQUIRE(images && anchors && out_boxes && out_scores && out_labels && out_counts && workspace, YOLO_ERR_ARG,
+                 "yolo_net_detect: null pointer");
+    YOLO_REQUIRE(B > 0 && max_boxes > 0, YOLO_ERR_ARG, "yolo_net_detect: non-positive size");
+    YOLO_REQUIRE(H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, YOLO_ERR_SHAPE, "yolo_net_detect: H, W must be multiples of 32 (got %dx%d)", H, W);
+    YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "yolo_net_detect: workspace must be 256-byte aligned");
+    const int lanes = lane_count(B);
+    DetectLayout lay[MAX_LANES];
+    size_t base[MAX_LANES + 1] = {0};
+    for (int i = 0; i < lanes; ++i) {
+        int rc = detect_layout(net, lane_batch(B, lanes, i), H, W, max_boxes, &lay[i]);
+        if (rc != YOLO_OK) return rc;
+        base[i + 1] = base[i] + lay[i].total;
     }
-    return rc;
+    YOLO_REQUIRE(workspace_bytes >= base[lanes], YOLO_ERR_WORKSPACE, "yolo_net_detect: workspace %zu < %zu bytes", workspace_bytes, base[lanes]);
+    const size_t cap = (size_t)net->class_num * max_boxes;
+    return run_lanes(net, lanes, B, (hipStream_t)stream, [&](int i, int b0, int Bi, hipStream_t s) {
+        char* w = (char*)workspace + base[i];
+        const DetectLayout& d = lay[i];
+        float* f1 = (float*)(w + d.fm[0]);
+        float* f2 = (float*)(w + d.fm[1]);
+        float* f3 = (float*)(w + d.fm[2]);
+        int rc = forward_impl(net, images + (size_t)b0 * H * W * 3, Bi, H, W, w + d.fwd, d.fm[0] - d.fwd, f1, f2, f3, s, nullptr);
+        if (rc != YOLO_OK) return rc;
+        return yolo_detect_post(f1, f2, f3, Bi, H, W, net->class_num, anchors, max_boxes, score_thresh, iou_thresh,
+                                out_boxes + (size_t)b0 * cap * 4, out_scores + (size_t)b0 * cap, out_labels + (size_t)b0 * cap,
+                                out_index ? out_index + (size_t)b0 * cap : nullptr, out_counts + b0, w + d.post, d.total - d.post, s);
+    });
 }
 
 extern "C" int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,

@@ -28,6 +28,7 @@ class yolov3(object):
         self._net = None
         self._ws = None
         self._post_ws = None
+        self._det_ws = None
         self.img_size = None
 
     # ---- weights (replaces tf.train.Saver.restore at test_single_image.py:35-36) -----------------
@@ -108,9 +109,37 @@ class yolov3(object):
         """The hot chain of test_single_image.py:31-40 for a batch, per image: forward -> predict ->
         conf*prob -> per-class NMS.  Defaults are that script's thresholds (:39).
         -> (boxes [N,C*max_boxes,4], scores, labels int32, keep-index int32, counts int32 [N]).
-        predict, the score product and gpu_nms run as ONE library call (yolo_detect_post): identical
-        results to the separate calls (detect_unfused), without the [N,n,C] probs / scores tensors."""
-        return self.postprocess(self.forward(inputs), max_boxes, score_thresh, iou_thresh)
+        ONE library call (yolo_net_detect): identical results to postprocess(forward(inputs)) and to the
+        reference's separate calls (detect_unfused), without the [N,n,C] probs / scores tensors; the feature maps
+        stay in the workspace and every lane post-processes its own images."""
+        if self._net is None:
+            raise RuntimeError("weights not loaded: call load_darknet_weights()/load_weight_stream() first")
+        x = _tensor.as_dev_f32(inputs)
+        if x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError("inputs must be [N, H, W, 3], got %s" % (tuple(x.shape),))
+        B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        self.img_size = (H, W)
+        C = self.class_num
+        anc = np.ascontiguousarray(self.anchors, np.float32)
+        if anc.shape != (9, 2):
+            raise ValueError("detect needs 9 anchors, got %s" % (anc.shape,))
+        L = _lib.lib()
+        need = L.yolo_net_detect_workspace_bytes(self._net, B, H, W, int(max_boxes))
+        if need == 0:
+            raise ValueError("detect: bad sizes B=%d H=%d W=%d C=%d max_boxes=%d (H, W must be multiples of 32)"
+                             % (B, H, W, C, max_boxes))
+        if self._det_ws is None or self._det_ws.numel() < need or self._det_ws.device != x.device:
+            self._det_ws = _tensor.workspace(need)
+        cap = C * int(max_boxes)
+        ob = _tensor.empty((B, cap, 4))
+        osc = _tensor.empty((B, cap))
+        ol = _tensor.empty((B, cap), torch.int32)
+        oi = _tensor.empty((B, cap), torch.int32)
+        oc = _tensor.empty((B,), torch.int32)
+        _lib.check(L.yolo_net_detect(self._net, x.data_ptr(), B, H, W, anc.ctypes.data, int(max_boxes), float(score_thresh),
+                                     float(iou_thresh), ob.data_ptr(), osc.data_ptr(), ol.data_ptr(), oi.data_ptr(),
+                                     oc.data_ptr(), self._det_ws.data_ptr(), self._det_ws.numel(), _tensor.stream_ptr()))
+        return ob, osc, ol, oi, oc
 
     def postprocess(self, feature_maps, max_boxes=30, score_thresh=0.4, iou_thresh=0.5):
         fm1, fm2, fm3 = [_tensor.as_dev_f32(f) for f in feature_maps]
