@@ -26,10 +26,11 @@ F32_PEAK_TFLOPS = 157.3
 # section 5): 2 x FETCH_SIZE + WRITE_SIZE averaged over the launches of one bench step (FETCH_SIZE doubled as
 # MI355X_MICROARCH.md "HBM" prescribes for gfx950).  Keyed by (kernel, batch, size); None when not measured.
 TRAFFIC_BYTES_PER_LAUNCH = {
-    # profiles/r1_bench_pmc_traffic_v3.txt: fetch 138.26 MB (2 x FETCH_SIZE) + write 35.69 MB
-    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, false>", 64, 416): 173.95e6,
-    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, true>", 64, 416): 245.70e6,
-    ("yolo::conv_igemm_kernel<true, 128, 128, 4, 2, 2>", 64, 416): 119.90e6,
+    # profiles/r1_bench_pmc_traffic_v4_lanes1.txt (one launch per layer over the full batch, as the roofline is measured):
+    # halo kernel, two patch buffers: fetch 138.92 MB (2 x FETCH_SIZE) + write 35.69 MB
+    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, false, 32>", 64, 416): 174.60e6,
+    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, true, 32>", 64, 416): 245.28e6,
+    ("yolo::conv_igemm_kernel<true, 128, 128, 4, 2, 2>", 64, 416): 119.49e6,
 }
 
 
@@ -84,10 +85,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--layer-table", default="", help="write the per-layer timing table to this file")
+    ap.add_argument("--lanes", type=int, default=0, help="sub-batches run concurrently on separate streams inside the library "
+                                                         "(YOLO_LANES); 0 = library default (2 from batch 12 up)")
     ap.add_argument("--h2d", action="store_true", help="also report the rate with the batch copied from pinned host memory "
                                                        "inside every step (extra key, never `value`)")
     args = ap.parse_args()
 
+    if args.lanes > 0:
+        os.environ["YOLO_LANES"] = str(args.lanes)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,7 +161,10 @@ def main():
     peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     traffic = TRAFFIC_BYTES_PER_LAUNCH.get((dom_name, B, S))
+    lanes = int(os.environ.get("YOLO_LANES", "0")) or (2 if B >= 12 else 1)
     roofline = {"bound": "mfma", "kernel": dom_name,
+                "measured": "HIP events around every layer of one launch per layer over the full batch (yolo_net_forward_timed); "
+                            "the timed steps run the same kernels as %d concurrent lane(s) of %d images" % (lanes, B // lanes),
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches_per_step": dom["launches"],
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
@@ -209,7 +217,8 @@ def main():
             "config": {"workload": "YOLOv3-%d COCO-80, batch %d per GPU, %s conv stack + fp32 decode + per-class NMS "
                                    "(max_boxes 50, score 0.5, iou 0.5), synthetic images and seeded random-init Darknet-order weights"
                                    % (S, B, args.dtype),
-                       "global_batch": world * B, "detections_last_step": ndet, "parallelism": "image-sharded dp%d" % world},
+                       "global_batch": world * B, "detections_last_step": ndet, "parallelism": "image-sharded dp%d" % world,
+                       "lanes_per_gpu": lanes},
             "roofline": roofline,
         }
         if h2d is not None:
