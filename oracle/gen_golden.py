@@ -151,6 +151,69 @@ def gen_nms():
     print("G3b", iou.shape, iou.dtype)
 
 
+def gen_eval():
+    """G5: the reference's recall / precision bookkeeping (eval_utils.py:23-88) on seeded ground truth + predictions."""
+    sys.modules["tensorflow"] = types.ModuleType("tensorflow")
+    sys.path.insert(0, os.path.join(REF, "yolo_v3"))
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[m]
+    from utils import eval_utils                          # reference module
+    rng = np.random.default_rng(51)
+    flat = {}
+    for name, N, C, n_noise, jitter, st, it in (("a", 3, 4, 150, 3.0, 0.5, 0.5), ("b", 2, 6, 400, 8.0, 0.3, 0.45),
+                                                 ("dup", 2, 3, 60, 1.0, 0.2, 0.5)):
+        grids = (4, 8, 16)
+        y_true = [np.zeros((N, g, g, 3, 5 + C), np.float32) for g in grids]
+        pb, pc, pp = [], [], []
+        for i in range(N):
+            boxes_i, conf_i, prob_i = [], [], []
+            for j, g in enumerate(grids):
+                k = int(rng.integers(2, 6))
+                for _ in range(k):
+                    y, x, a = int(rng.integers(0, g)), int(rng.integers(0, g)), int(rng.integers(0, 3))
+                    cx, cy = rng.random(2) * 120 + 4
+                    w, h = rng.random(2) * 40 + 6
+                    c = int(rng.integers(0, C))
+                    y_true[j][i, y, x, a, 0:4] = (cx, cy, w, h)
+                    y_true[j][i, y, x, a, 4] = 1.0
+                    y_true[j][i, y, x, a, 5 + c] = 1.0
+                    reps = 3 if name == "dup" else int(rng.integers(0, 3))       # several predictions on one object
+                    for _ in range(reps):
+                        d = rng.normal(0, jitter, 4)
+                        boxes_i.append([cx - w / 2 + d[0], cy - h / 2 + d[1], cx + w / 2 + d[2], cy + h / 2 + d[3]])
+                        conf_i.append(0.6 + 0.4 * rng.random())
+                        p = rng.random(C) * 0.2
+                        p[c if rng.random() < 0.8 else int(rng.integers(0, C))] = 0.7 + 0.3 * rng.random()
+                        prob_i.append(p)
+            for _ in range(n_noise):
+                xy = rng.random(2) * 120
+                wh = rng.random(2) * 30 + 2
+                boxes_i.append([xy[0], xy[1], xy[0] + wh[0], xy[1] + wh[1]])
+                conf_i.append(rng.random() * 0.7)
+                prob_i.append(rng.random(C))
+            pb.append(boxes_i); pc.append(conf_i); pp.append(prob_i)
+        n = max(len(b) for b in pb)
+        for i in range(N):                                  # pad to a common n with zero-score boxes
+            while len(pb[i]) < n:
+                pb[i].append([0, 0, 1, 1]); pc[i].append(0.0); pp[i].append(np.zeros(C))
+        y_pred = [np.asarray(pb, np.float32), np.asarray(pc, np.float32)[..., None], np.asarray(pp, np.float32)]
+        tp, tl, pl = eval_utils.evaluate_on_cpu([a.copy() for a in y_pred], [a.copy() for a in y_true], C, calc_now=False,
+                                                score_thresh=st, iou_thresh=it)
+        rec, prec = eval_utils.evaluate_on_cpu([a.copy() for a in y_pred], [a.copy() for a in y_true], C, calc_now=True,
+                                               score_thresh=st, iou_thresh=it)
+        for j in range(3):
+            flat["%s/y_true%d" % (name, j)] = y_true[j]
+        flat[name + "/pred_boxes"], flat[name + "/pred_confs"], flat[name + "/pred_probs"] = y_pred
+        flat[name + "/C"] = np.int32(C)
+        flat[name + "/score_thresh"], flat[name + "/iou_thresh"] = np.float32(st), np.float32(it)
+        flat[name + "/true_positive"] = np.asarray([tp[c] for c in range(C)], np.int64)
+        flat[name + "/true_labels"] = np.asarray([tl[c] for c in range(C)], np.int64)
+        flat[name + "/pred_labels"] = np.asarray([pl[c] for c in range(C)], np.int64)
+        flat[name + "/recall_precision"] = np.asarray([rec, prec], np.float64)
+        print("G5", name, dict(tp), dict(tl), dict(pl), rec, prec)
+    np.savez_compressed(os.path.join(OUT, "g5_eval.npz"), **flat)
+
+
 def gen_v2_decode():
     sys.modules["tensorflow"] = types.ModuleType("tensorflow")
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
@@ -195,5 +258,7 @@ if __name__ == "__main__":
         gen_v2_decode()
     if "nms" in which:
         gen_nms()
+    if "eval" in which:
+        gen_eval()
     if "conv" in which:
         gen_conv_and_decode()
