@@ -531,3 +531,17 @@ def test_detect_one_call_equals_forward_then_postprocess(net_bf16, net_f32):
         net_f32.detect(np.zeros((1, 40, 64, 3), np.float32))
     with pytest.raises(ValueError):
         net_f32.detect(np.zeros((1, 64, 64, 3), np.float32), max_boxes=0)
+
+
+def test_load_state_equals_load_weight_stream(net_f32, weight_stream, tmp_path):
+    """a checkpoint in the reference's TF variable naming (convert_weight counterpart) loads to the same network."""
+    import torch
+    from yolo_amd import weights
+    from yolo_amd.model import yolov3
+    from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
+    ck = str(tmp_path / "ck.npz")
+    np.savez(ck, **weights.stream_to_state(weight_stream, 80))
+    net = yolov3(80, DEFAULT_ANCHORS, dtype="fp32").load_state(ck)
+    x = np.random.default_rng(37).random((1, 64, 64, 3), dtype=np.float32)
+    for a, b in zip(net.forward(x), net_f32.forward(x)):
+        assert torch.equal(a, b)

@@ -93,3 +93,33 @@ def test_misc_utils_parsers(tmp_path):
     assert misc_utils.read_class_names(str(n)) == {0: "person", 1: "bicycle", 2: "car"}
     names = misc_utils.coco_class_names()
     assert len(names) == 80 and names[0] == "person" and names[16] == "dog" and names[79] == "toothbrush"
+
+
+def test_convert_weight_checkpoint_roundtrip(tmp_path, weight_stream):
+    """convert_weight counterpart: .weights -> .npz in the reference's TF variable naming -> the same stream."""
+    from yolo_amd import convert_weight, weights
+    wf, ck = str(tmp_path / "y.weights"), str(tmp_path / "y.npz")
+    weights.write_darknet_weights(wf, weight_stream)
+    state = convert_weight.convert(wf, ck, 80)
+    assert len(state) == 72 * 5 + 3 * 2
+    assert state["yolov3/darknet53_body/Conv/weights"].shape == (3, 3, 3, 32)
+    assert state["yolov3/darknet53_body/Conv_51/BatchNorm/moving_variance"].shape == (1024,)
+    assert state["yolov3/yolov3_head/Conv_6/biases"].shape == (255,) and state["yolov3/yolov3_head/Conv_22/weights"].shape == (1, 1, 256, 255)
+    # first conv: the file holds beta, gamma, mean, var, then the kernel as [Cout, Cin, kh, kw] (misc_utils.py:66-90)
+    assert np.array_equal(state["yolov3/darknet53_body/Conv/BatchNorm/beta"], weight_stream[:32])
+    assert np.array_equal(state["yolov3/darknet53_body/Conv/BatchNorm/gamma"], weight_stream[32:64])
+    k = weight_stream[128:128 + 32 * 27].reshape(32, 3, 3, 3)
+    assert np.array_equal(state["yolov3/darknet53_body/Conv/weights"], np.transpose(k, (2, 3, 1, 0)))
+    with np.load(ck, allow_pickle=False) as z:
+        back = weights.state_to_stream({n + ":0": z[n] for n in z.files}, 80)
+    assert np.array_equal(back, weight_stream)
+    bad = dict(state)
+    del bad["yolov3/yolov3_head/Conv_6/biases"]
+    with pytest.raises(KeyError):
+        weights.state_to_stream(bad, 80)
+    bad = dict(state)
+    bad["yolov3/extra/weights"] = np.zeros(3, np.float32)
+    with pytest.raises(ValueError):
+        weights.state_to_stream(bad, 80)
+    with pytest.raises(ValueError):
+        convert_weight.convert(wf, ck, 20)

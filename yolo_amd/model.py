@@ -46,6 +46,16 @@ class yolov3(object):
     def load_darknet_weights(self, weights_file):
         return self.load_weight_stream(misc_utils.read_darknet_weights(weights_file))
 
+    def load_state(self, state):
+        """state: path of an .npz written by `python -m yolo_amd.convert_weight` / `save_state`, or a dict of arrays
+        named like the reference's TF variables (`yolov3/darknet53_body/Conv_3/BatchNorm/gamma`, ... - what a
+        maintainer dumps from their converted checkpoint).  Replaces Saver.restore (test_single_image.py:35-36)."""
+        from . import weights
+        if not isinstance(state, dict):
+            with np.load(state, allow_pickle=False) as z:
+                state = {k: z[k] for k in z.files}
+        return self.load_weight_stream(weights.state_to_stream(state, self.class_num))
+
     def _free(self):
         if getattr(self, "_net", None) is not None:
             _lib.lib().yolo_net_destroy(self._net)

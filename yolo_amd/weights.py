@@ -100,3 +100,63 @@ def write_darknet_weights(path, stream, header=(0, 2, 0, 0, 0)):
     with open(path, "wb") as fp:
         np.asarray(header, np.int32).tofile(fp)
         np.asarray(stream, np.float32).tofile(fp)
+
+
+# ---- checkpoint ("state") in the reference's TF variable naming ---------------------------------------------------
+def tf_variable_prefixes(class_num=80):
+    """Scope of every conv's variables in the graph the reference builds under `tf.variable_scope('yolov3')`
+    (convert_weight.py:21-25): slim numbers the convs per scope in creation order - `darknet53_body/Conv`,
+    `Conv_1` .. `Conv_51` (model.py:38-39), then `yolov3_head/Conv` .. `Conv_22` (model.py:40-64)."""
+    specs = yolov3_conv_specs(class_num)
+    out = []
+    for i in range(len(specs)):
+        scope, j = ("darknet53_body", i) if i < 52 else ("yolov3_head", i - 52)
+        out.append("yolov3/%s/%s" % (scope, "Conv" if j == 0 else "Conv_%d" % j))
+    return out
+
+
+def stream_to_state(stream, class_num=80):
+    """Darknet-order stream -> dict of arrays named and laid out like the reference's TF variables after
+    load_weights (misc_utils.py:59-95): `<conv>/weights` HWIO, `<conv>/BatchNorm/{gamma,beta,moving_mean,
+    moving_variance}` or `<conv>/biases`."""
+    state = {}
+    for prefix, d in zip(tf_variable_prefixes(class_num), split_stream(np.asarray(stream, np.float32), class_num)):
+        state[prefix + "/weights"] = d["w"]
+        if d["spec"]["bn"]:
+            for key, name in (("gamma", "gamma"), ("beta", "beta"), ("mean", "moving_mean"), ("var", "moving_variance")):
+                state[prefix + "/BatchNorm/" + name] = d[key]
+        else:
+            state[prefix + "/biases"] = d["bias"]
+    return state
+
+
+def state_to_stream(state, class_num=80):
+    """Inverse of stream_to_state.  Names may carry a ':0' suffix and may lack the leading 'yolov3/'."""
+    norm = {}
+    for name, v in state.items():
+        name = name[:-2] if name.endswith(":0") else name
+        norm[name if name.startswith("yolov3/") else "yolov3/" + name] = np.asarray(v, np.float32)
+    parts, used = [], set()
+
+    def take(name, shape):
+        if name not in norm:
+            raise KeyError("state has no variable %r" % name)
+        v = norm[name]
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError("variable %r has shape %s, architecture needs %s" % (name, tuple(v.shape), tuple(shape)))
+        used.add(name)
+        return v
+
+    for prefix, s in zip(tf_variable_prefixes(class_num), yolov3_conv_specs(class_num)):
+        co = s["cout"]
+        if s["bn"]:
+            for name in ("beta", "gamma", "moving_mean", "moving_variance"):        # file order (misc_utils.py:68-69)
+                parts.append(take(prefix + "/BatchNorm/" + name, (co,)).ravel())
+        else:
+            parts.append(take(prefix + "/biases", (co,)).ravel())
+        w = take(prefix + "/weights", (s["k"], s["k"], s["cin"], co))
+        parts.append(np.transpose(w, (3, 2, 0, 1)).ravel())                          # HWIO -> [Cout, Cin, kh, kw]
+    extra = sorted(set(norm) - used)
+    if extra:
+        raise ValueError("state has %d variables the architecture does not: %s ..." % (len(extra), extra[:3]))
+    return np.concatenate(parts).astype(np.float32)
