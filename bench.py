@@ -182,6 +182,29 @@ def main():
                 f.write("%2d %4d %4d %d %d %8.4f %9.3f %8.2f  %s\n" % (i, cin, cout, k, s, ms_i, flops[i] * B / 1e9,
                                                                        flops[i] * B / (ms_i * 1e-3) / 1e12, kernels[i]))
 
+    # ---- post-processing alone (decode + conf*prob + score mask + per-class NMS, fused: yolo_detect_post) on the feature
+    # maps of the last forward: HBM-bound by SURVEY.md 8(d); algorithmic bytes per image = decode 7.24 MB (read 3 fms,
+    # write boxes + confs + probs) + NMS 3.58 MB (read boxes + scores) at 416 - what the separate reference calls move
+    fms = net.forward(images)
+    for _ in range(3):
+        net.postprocess(fms, 50, 0.5, 0.5)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        net.postprocess(fms, 50, 0.5, 0.5)
+    ev1.record()
+    torch.cuda.synchronize()
+    post_ms = ev0.elapsed_time(ev1) / 20
+    n_boxes = 3 * ((S // 32) ** 2 + (S // 16) ** 2 + (S // 8) ** 2)
+    post_bytes = B * (2.0 * n_boxes * 85 * 4 + n_boxes * 84 * 4)
+    fused_bytes = B * (n_boxes * 85 * 4 + n_boxes * 16)            # what the fused call must move: read fms, write boxes
+    post = {"bound": "hbm", "ms": round(post_ms, 4), "peak": 8000.0, "unit": "GB/s",
+            "achieved": round(post_bytes / (post_ms * 1e-3) / 1e9, 1), "frac": round(post_bytes / (post_ms * 1e-3) / 8e12, 4),
+            "achieved_fused_bytes": round(fused_bytes / (post_ms * 1e-3) / 1e9, 1),
+            "what": "yolo_detect_post on %d images (%d boxes x 80 classes each, thresholds 50 / 0.5 / 0.5), HIP events on the launch stream; "
+                    "`achieved` prices the algorithmic bytes of the reference's separate predict + gpu_nms calls (10.82 MB/img), "
+                    "`achieved_fused_bytes` the 3.79 MB/img the fused call really has to move" % (B, n_boxes)}
+
     h2d = None
     if args.h2d:
         from yolo_amd.preprocess import preprocess
@@ -221,6 +244,7 @@ def main():
                        "lanes_per_gpu": lanes},
             "roofline": roofline,
         }
+        res["post_processing"] = post
         if h2d is not None:
             res["pcie_inclusive"] = h2d
         if world == 1 and not args.no_cpu_baseline:
