@@ -545,3 +545,22 @@ def test_load_state_equals_load_weight_stream(net_f32, weight_stream, tmp_path):
     x = np.random.default_rng(37).random((1, 64, 64, 3), dtype=np.float32)
     for a, b in zip(net.forward(x), net_f32.forward(x)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cfg", ["40", "41", "34", "38", "26", "5"])
+def test_alternative_conv_tilings_vs_oracle(net_bf16, oracle, oracle_params, cfg):
+    """the selectable tile configurations (YOLO_CONV_CFG: 40 / 41 = 256- / 192-row ping-pong tiles on 16x16x32 MFMAs,
+    34 / 38 = the shipped tiling on 16x16x32 MFMAs, 26 = 16-wave tile, 5 = im2col) meet the bf16 tolerance of
+    test_forward_bf16_vs_oracle against the oracle."""
+    import os
+    img = np.random.default_rng(43).random((3, 96, 160, 3), dtype=np.float32)
+    ref = oracle.forward(oracle_params, img)
+    os.environ["YOLO_CONV_CFG"] = cfg
+    try:
+        got = [f.cpu().numpy() for f in net_bf16.forward(img)]
+    finally:
+        del os.environ["YOLO_CONV_CFG"]
+    for a, b in zip(got, ref):
+        ok, maxerr, rms = rel_rms_ok(a, b, 1e-1)
+        assert ok, (cfg, b.shape, maxerr, rms)
+        assert float(np.sqrt(np.mean((a - b) ** 2))) <= 3e-2 * rms

@@ -631,6 +631,320 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
 #endif
 }
 
+// ---- 3x3 stride-1 convolution, 256x256 tile, ping-pong wave rows ("p8", bf16 only) -----------------------------------
+// The LDS-resident patch of conv3x3_halo_kernel under the GEMM schedule measured in scripts/probe/gemm8p.hip (1.0-1.2
+// PFLOP/s on random bf16 data against ~0.83 for the 128x128 / two-workgroup structure above):
+//   * one workgroup of 8 waves per CU, 2 (pixel rows) x 4 (channels); a wave owns 128 pixels x 64 channels as 8 x 4 tiles of
+//     v_mfma_f32_16x16x32_bf16 (128 accumulator VGPRs): 24 ds_read_b128 per 64 MFMAs instead of 12 per 8
+//   * a K-step is one (128-byte channel chunk, tap) pair in four phases of 16 MFMAs (one 64 x 32 quadrant); fragment
+//     reads 12 / 4 / 8 / 0 per phase; the two wave rows run half a phase apart (two barriers per phase), so one row's MFMAs
+//     cover the other row's LDS reads and LDS-DMA issue
+//   * the next step's weight tile [256 x 128 B] is requested in phases 0-2 (1 / 2 / 1 LDS-DMAs per wave), the next chunk's
+//     patch one piece per wave and step behind them, so that the counted vmcnt of phase 3 waits for the weights only and
+//     a patch piece has two steps to arrive
+// Patch geometry, tap masks, zero row, swizzle, weight packing: exactly as in conv3x3_halo_kernel.
+template <int MT>
+__global__ __launch_bounds__(512) void conv3x3_p8_kernel(ConvK p, int prows) {
+    constexpr int QH = 16 * MT;                 // pixel rows of a quadrant; a wave owns 2 QH rows, the tile 4 QH
+    constexpr int RH = 2 * QH;
+    constexpr int BM = 2 * RH, BN = 256;
+    constexpr int B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = tile / p.ntn;
+    const int nt = tile - mt * p.ntn;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int W = p.W;
+    const int CinB = p.Cin * 2;
+    const int nchunks = CinB >> 7;
+    const int patch_bytes = prows * 128;
+    char* const patch0 = lds;
+    char* const bbuf0 = lds + (nchunks > 1 ? 2 : 1) * patch_bytes;
+    char* const zrow = bbuf0 + 2 * B_BYTES;
+    if (tid < 32) ((unsigned*)zrow)[tid] = 0u;
+
+    // ---- loader state (see conv3x3_halo_kernel)
+    const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const int ngroups = prows >> 3;
+    const int qlane = m0 - W - 1 + (lane >> 3);
+    const unsigned pix_b = (unsigned)(p.in_ld * 2);
+    const char* const in_base = p.in + (long long)p.in_coff * 2;
+    const char* const w_base = p.w + (long long)n0 * p.kpad_bytes;
+    unsigned w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w_off[i] = (unsigned)(8 * (wave + 8 * i) + (lane >> 3)) * (unsigned)p.kpad_bytes + chunk * 16;
+    auto load_patch_piece = [&](int c, int g) {
+        int q = qlane + 8 * g;
+        q = q < 0 ? 0 : (q >= p.M ? p.M - 1 : q);
+        const unsigned off = (unsigned)q * pix_b + chunk * 16;
+        GLDS16(in_base + c * 128 + off, patch0 + (c & 1) * patch_bytes + g * 1024);
+    };
+    auto load_b = [&](int c, int t, int buf, int i) {            // piece wave + 8 i of the weight tile of (chunk c, tap t)
+        GLDS16(w_base + ((long long)t * CinB + c * 128) + w_off[i], bbuf0 + buf * B_BYTES + (wave + 8 * i) * 1024);
+    };
+
+    // ---- fragment addressing (16x16x32: lane row = l & 15, 16-byte k-chunk = 4 kk + (l >> 4))
+    const int fr = lane & 15, fq = lane >> 4;
+    unsigned a_mask[2][MT];
+#pragma unroll
+    for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rt = wr * RH + mq * QH + i * 16 + fr;
+            const int m = m0 + rt;
+            unsigned mask = 0;
+            if (m < p.M) {
+                const int r = m % (p.H * W);
+                const int y = r / W, x = r - y * W;
+#pragma unroll
+                for (int tt = 0; tt < 9; ++tt) {
+                    const int iy = y + tt / 3 - 1, ix = x + tt % 3 - 1;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < W) mask |= 1u << tt;
+                }
+            }
+            a_mask[mq][i] = mask;
+        }
+    unsigned b_off[2][2];
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wc * 64 + nq * 32 + j * 16 + fr;
+            b_off[nq][j] = row * 128 + ((fq ^ ((row >> 1) & 7)) << 4);
+        }
+
+    f32x4 acc[2][MT][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 af[MT][2], bf0[2][2], bf1[2][2];
+
+#define P8_BAR()                            \
+    do {                                    \
+        __builtin_amdgcn_sched_barrier(0);  \
+        __builtin_amdgcn_s_barrier();       \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+#define P8_LGKM0()                                           \
+    do {                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                   \
+    } while (0)
+
+    // rows of one lane's eight A fragments are 16 apart, so they share the swizzle term ((row >> 1) & 7): one base
+    // offset per tap, the fragments at constant distances from it
+    const int zrow_off = (int)(zrow - lds) + (fq << 4);
+    const int rt0 = wr * RH + fr;
+    int a_base = 0;
+    auto set_tap = [&](const char* patch, int shift) {
+        const int prow0 = rt0 + shift;
+        a_base = (int)(patch - lds) + prow0 * 128 + ((fq ^ ((prow0 >> 1) & 7)) << 4);
+    };
+    auto read_a = [&](int mq, int t) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const bool ok = (a_mask[mq][i] >> t) & 1;
+            const int off = ok ? a_base + (mq * QH + i * 16) * 128 : zrow_off;   // masked tap: zeros
+            af[i][0] = *(const u32x4*)(lds + off);
+            af[i][1] = *(const u32x4*)(lds + (off ^ 64));
+        }
+    };
+    auto read_b = [&](const char* bbase, int nq, u32x4 (&bf)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf[j][0] = *(const u32x4*)(bbase + b_off[nq][j]);
+            bf[j][1] = *(const u32x4*)(bbase + (b_off[nq][j] ^ 64));
+        }
+    };
+    auto mfma_quadrant = [&](int mq, int nq, u32x4 (&bf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mq][i][nq][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, af[i][kk]), __builtin_bit_cast(bf16x8, bf[j][kk]), acc[mq][i][nq][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: patch of chunk 0 + weight tile (0,0); the second wave row then falls one barrier behind
+    for (int g = wave; g < ngroups; g += 8) load_patch_piece(0, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_b(0, 0, 0, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_BAR();
+    if (wr == 1) P8_BAR();
+
+    int bcur = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const char* patch = patch0 + (c & 1) * patch_bytes;
+        const bool next_chunk = c + 1 < nchunks;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int ky = (t * 11) >> 5, kx = t - ky * 3;
+            const int shift = ky * W + kx;
+            const char* bbase = bbuf0 + bcur * B_BYTES;
+            const bool more = t < 8 || next_chunk;
+            const int nc = t < 8 ? c : c + 1, ntap = t < 8 ? t + 1 : 0, nb = bcur ^ 1;
+            const int piece = t * 8 + wave;                       // patch piece of the next chunk this wave requests in this step
+            const bool has_piece = next_chunk && piece < ngroups;
+            // phase 0: quadrant (0,0)
+            set_tap(patch, shift);
+            read_b(bbase, 0, bf0);
+            read_a(0, t);
+            if (more) load_b(nc, ntap, nb, 0);
+            P8_BAR();
+            P8_LGKM0();
+            mfma_quadrant(0, 0, bf0);
+            P8_BAR();
+            // phase 1: quadrant (0,1)
+            read_b(bbase, 1, bf1);
+            if (more) { load_b(nc, ntap, nb, 1); load_b(nc, ntap, nb, 2); }
+            P8_BAR();
+            P8_LGKM0();
+            mfma_quadrant(0, 1, bf1);
+            P8_BAR();
+            // phase 2: quadrant (1,1)
+            read_a(1, t);
+            if (more) load_b(nc, ntap, nb, 3);
+            if (has_piece) load_patch_piece(c + 1, piece);        // youngest load of the step
+            P8_BAR();
+            P8_LGKM0();
+            mfma_quadrant(1, 1, bf1);
+            P8_BAR();
+            // phase 3: quadrant (1,0) out of registers.  Before the barrier that lets the other wave row read the next
+            // weight tile, this wave's share of it has landed; a patch piece may stay in flight except before a new chunk.
+            if (wr == 1) {
+                if (has_piece && t < 8) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            P8_BAR();
+            mfma_quadrant(1, 0, bf0);
+            if (wr == 0) {
+                if (has_piece && t < 8) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            P8_BAR();
+            bcur = nb;
+        }
+    }
+    if (wr == 0) P8_BAR();                      // both wave rows have passed the same number of barriers
+
+    // ---- epilogue in two passes (pixel rows mq*64 .. +63 of both wave rows): bias + activation -> f32 staging in LDS
+    // [2 QH][260] -> per thread (pixel, 8 channels): residual add, bf16, 16-byte store
+    constexpr int LDC = BN + 4;
+    float* const ct = (float*)lds;
+    for (int mq = 0; mq < 2; ++mq) {
+        if (mq == 1) P8_BAR();                  // staging of pass 0 fully read
+        auto to_lds = [&](auto mode) {
+            constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = wc * 64 + nq * 32 + j * 16 + fr;
+                    const float bv = p.bias[n0 + col];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = wr * QH + i * 16 + 4 * fq + r;
+                            float v = (mq == 0 ? acc[0][i][nq][j][r] : acc[1][i][nq][j][r]) + bv;
+                            if constexpr (MODE == 1) v = leaky_v3(v);
+                            else if constexpr (MODE == 2) v = __builtin_fmaxf(0.1f * v, v);
+                            ct[row * LDC + col] = v;
+                        }
+                }
+        };
+        if (p.leaky == 1) to_lds(std::integral_constant<int, 1>{});
+        else if (p.leaky == 2) to_lds(std::integral_constant<int, 2>{});
+        else to_lds(std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P8_BAR();
+        constexpr int ITERS = RH * (BN / 8) / 512;      // 2 MT
+        u32x4 rres[ITERS];
+        if (p.res) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid + it * 512;
+                const int row = idx >> 5, ch = idx & 31;
+                const int m = m0 + (row / QH) * RH + mq * QH + (row % QH);
+                const bool ok = m < p.M;
+                rres[it] = *(const u32x4*)(p.res + ((long long)(ok ? m : 0) * p.res_ld + p.res_coff + n0 + ch * 8) * 2);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * 512;
+            const int row = idx >> 5, ch = idx & 31;
+            const int m = m0 + (row / QH) * RH + mq * QH + (row % QH);
+            if (m >= p.M) continue;
+            const f32x4 v0 = *(const f32x4*)(ct + row * LDC + ch * 8);
+            const f32x4 v1 = *(const f32x4*)(ct + row * LDC + ch * 8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (p.res) {
+                const bf16x8 rv = __builtin_bit_cast(bf16x8, rres[it]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            *(bf16x8*)(p.out + ((long long)m * p.out_ld + p.out_coff + n0 + ch * 8) * 2) = o;
+        }
+    }
+#undef P8_BAR
+#undef P8_LGKM0
+}
+
+template <int MT>
+static int launch_p8(const ConvK& k, hipStream_t stream) {
+    constexpr int BM = 64 * MT;
+    const int prows = (int)align_up((size_t)(BM + 2 * k.W + 2), 8);
+    const int nchunks = k.Cin * 2 / 128;
+    const int loop_bytes = (nchunks > 1 ? 2 : 1) * prows * 128 + 2 * 256 * 128 + 128;
+    constexpr int epi_bytes = 32 * MT * (256 + 4) * 4;
+    const int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
+    YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 p8: W=%d needs %d bytes of LDS", k.W, lds_bytes);
+    YOLO_REQUIRE(prows <= 512, YOLO_ERR_UNSUPPORTED, "conv3x3 p8: W=%d too wide", k.W);
+    YOLO_REQUIRE(k.Cout % 256 == 0, YOLO_ERR_UNSUPPORTED, "conv3x3 p8: Cout=%d not a multiple of 256", k.Cout);
+    YOLO_REQUIRE((long long)k.M * k.in_ld * 2 < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 p8: input larger than 4 GiB");
+    auto fn = conv3x3_p8_kernel<MT>;
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    YOLO_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_done[dev]) {
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev < 16) attr_done[dev] = true;
+    }
+    ConvK kk = k;
+    kk.ntm = (k.M + BM - 1) / BM;
+    kk.ntn = k.Cout / 256;
+    note_kernel("yolo::conv3x3_p8_kernel<%d>", MT);
+    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(512), lds_bytes, stream, kk, prows);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
 template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32>
 static int launch_halo(const ConvK& k, hipStream_t stream) {
     if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32>(k, stream);
@@ -683,11 +997,11 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     return YOLO_OK;
 }
 
-// Tile configurations.  YOLO_CONV_CFG=<id> (environment, read once) forces one for experiments.
+// Tile configurations.  YOLO_CONV_CFG=<id> (environment) forces one for experiments and tests.
 template <bool BF16>
 static int launch_dtype(const ConvK& k, hipStream_t stream) {
-    static const int forced = [] { const char* e = getenv("YOLO_CONV_CFG"); return e ? atoi(e) : -1; }();
-    int cfg = forced;
+    const char* forced = getenv("YOLO_CONV_CFG");              // read per call: the tests toggle it
+    int cfg = forced ? atoi(forced) : -1;
     const int sz = BF16 ? 2 : 4;
     const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32 && !k.reorg;
     if (cfg >= 20 && !halo_ok) cfg = -1;
@@ -723,6 +1037,11 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 26: return launch_halo<BF16, 256, 128, 8, 2>(k, stream);      // 16 waves, 1 block/CU
         case 27: return launch_halo<BF16, 256, 128, 4, 4>(k, stream);
         case 28: return launch_halo<BF16, 128, 128, 4, 2, true>(k, stream);   // single patch buffer: 2 blocks/CU up to W ~ 60
+        case 40: case 41: case 42:                                          // 256 / 192 / 128 x 256 ping-pong tile, bf16 only
+            if constexpr (BF16) {
+                if (k.Cout % 256 == 0) return cfg == 40 ? launch_p8<4>(k, stream) : cfg == 41 ? launch_p8<3>(k, stream) : launch_p8<2>(k, stream);
+            }
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 34: return launch_halo<BF16, 128, 128, 4, 2, false, 16>(k, stream);   // 24 / 28 out of 16x16x32 MFMAs
         case 38: return launch_halo<BF16, 128, 128, 4, 2, true, 16>(k, stream);
         case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
