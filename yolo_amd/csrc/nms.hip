@@ -14,9 +14,9 @@
 //                    at a time: test against the selected boxes (LDS), build the 64x64 IoU bitmask
 //                    of the chunk (one 64-bit word per lane), run the LDS-resident suppression scan,
 //                    append the survivors; stops at max_boxes.
-//        k  > 2048 : (eval-mode stress, score_thresh 0.001) repeated "best alive candidate" passes:
-//                    every pass kills what the last selected box suppresses and min-reduces the
-//                    surviving keys; at most max_boxes passes, no sort.
+//        k  > 2048 : (eval-mode stress, score_thresh 0.001) the same walk over successive key ranges of at most
+//                    2048 candidates, best first, cut out by a radix histogram of the keys; stops as soon as
+//                    max_boxes boxes are selected (normally inside the first range).
 //  3. nms_gather  : per image, prefix over class counts -> class-ordered dense output rows.
 #include "decode_common.h"
 
@@ -226,6 +226,13 @@ __global__ __launch_bounds__(256) void decode_sparse_kernel(DecodeK k, float thr
 }
 
 // ---- 2. selection ------------------------------------------------------------------------------
+// One workgroup per (image, class).  The candidates are consumed in key order (best first) in ROUNDS of at most
+// kSortCap keys: a round takes the key range [lo, hi), sorts it in LDS and lets wave 0 walk it.  Greedy NMS only ever
+// looks back (a candidate is judged against better-ranked ones), so the first max_boxes survivors of the whole list
+// are found as soon as a prefix of it has produced them - with k = 22743 candidates per class (score_thresh 0.001)
+// the first round normally does.  hi comes from a radix histogram of the keys >= lo: 12 key bits per level, descending
+// into the first non-empty bin while that bin alone holds more than kSortCap keys (equal scores differ only in the
+// index bits); keys are unique, so the last level always separates them.
 template <int MODE>
 __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict__ boxes, int n, int C, int max_boxes,
                                                          float iou_thr, const int* __restrict__ cand_count,
@@ -234,8 +241,9 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
     __shared__ u64 skeys[kSortCap];
     __shared__ f32x4 selbox[kSelCap];
     __shared__ u64 masks[64];
-    __shared__ u64 wbest[4];
-    __shared__ u64 bcast_key;
+    __shared__ int hist[4096];
+    __shared__ int part[256];
+    __shared__ int s_take, s_first, s_cnt, s_nsel;
 
     const int bc = blockIdx.x;                 // b * C + c
     const int b = bc / C;
@@ -244,113 +252,144 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
     int* out_idx = sel_idx + (long long)bc * max_boxes;
     float* out_sc = sel_score ? sel_score + (long long)bc * max_boxes : nullptr;   // scores live only in the keys (fused path)
     const f32x4* bx = (const f32x4*)boxes + (long long)b * n;
-    u64* keys = cand_keys + (long long)bc * n;
+    const u64* keys = cand_keys + (long long)bc * n;
     if (k == 0) {
         if (tid == 0) sel_count[bc] = 0;
         return;
     }
 
-    if (k <= kSortCap) {
+    int nsel = 0;
+    u64 lo = 0;                                // every key < lo has been walked
+    while (true) {
+        // ---- the round's key range [lo, hi) and its keys -> skeys[0, cnt)
+        u64 hi = kDead;
+        if (k > kSortCap) {
+            u64 prefix = 0, pmask = 0;         // keys under consideration: key >= lo and (key & pmask) == prefix
+            int shift = 52, bits = 12;
+            while (true) {
+                const int nbins = 1 << bits;
+                for (int i = tid; i < nbins; i += 256) hist[i] = 0;
+                if (tid == 0) { s_take = -1; s_first = nbins; }
+                __syncthreads();
+                for (int i = tid; i < k; i += 256) {
+                    const u64 key = keys[i];
+                    if (key >= lo && (key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shift) & (u64)(nbins - 1))], 1);
+                }
+                __syncthreads();
+                // inclusive prefix sums over the bins: thread t owns bins [t * per, (t + 1) * per)
+                const int per = nbins >= 256 ? nbins / 256 : 1;
+                const int nown = nbins >= 256 ? 256 : nbins;
+                int mine = 0;
+                if (tid < nown)
+                    for (int j = 0; j < per; ++j) mine += hist[tid * per + j];
+                part[tid] = mine;
+                __syncthreads();
+                if (tid == 0) {
+                    int acc = 0;
+                    for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = acc; acc += v; }   // exclusive
+                }
+                __syncthreads();
+                if (tid < nown) {
+                    int acc = part[tid];
+                    for (int j = 0; j < per; ++j) {
+                        const int h = hist[tid * per + j];
+                        acc += h;
+                        if (h > 0) {
+                            atomicMin(&s_first, tid * per + j);
+                            if (acc <= kSortCap) atomicMax(&s_take, tid * per + j);       // bins 0..this one fit a round
+                        }
+                    }
+                }
+                __syncthreads();
+                const int take = s_take, first = s_first;
+                __syncthreads();
+                if (first == nbins) { hi = lo; break; }                                    // no key >= lo left
+                if (take >= 0) {                                                           // whole bins [.., take] fit
+                    hi = prefix + ((u64)(take + 1) << shift);
+                    if ((shift == 52 && take + 1 == nbins) || hi < prefix) hi = kDead;      // past the largest key
+                    break;
+                }
+                // the first non-empty bin alone exceeds a round: split it by the next key bits
+                prefix |= (u64)first << shift;
+                pmask |= (u64)(nbins - 1) << shift;
+                if (shift >= 12) { shift -= 12; bits = 12; }
+                else { bits = shift; shift = 0; }                                          // 64 = 5 x 12 + 4
+            }
+            if (hi == lo) break;
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            for (int i = tid; i < k; i += 256) {
+                const u64 key = keys[i];
+                if (key >= lo && key < hi) skeys[atomicAdd(&s_cnt, 1)] = key;
+            }
+            __syncthreads();
+        } else {
+            for (int i = tid; i < k; i += 256) skeys[i] = keys[i];
+            if (tid == 0) s_cnt = k;
+            __syncthreads();
+        }
+        const int cnt = s_cnt;
         int np2 = 64;
-        while (np2 < k) np2 <<= 1;
-        for (int i = tid; i < np2; i += 256) skeys[i] = i < k ? keys[i] : kDead;
+        while (np2 < cnt) np2 <<= 1;
+        for (int i = cnt + tid; i < np2; i += 256) skeys[i] = kDead;
         __syncthreads();
         for (int size = 2; size <= np2; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
                 for (int t = tid; t < (np2 >> 1); t += 256) {
-                    const int lo = 2 * t - (t & (stride - 1));
-                    const int hi = lo + stride;
-                    const bool up = (lo & size) == 0;
-                    const u64 x = skeys[lo], y = skeys[hi];
-                    if ((x > y) == up) { skeys[lo] = y; skeys[hi] = x; }
+                    const int l0 = 2 * t - (t & (stride - 1));
+                    const int h0 = l0 + stride;
+                    const bool up = (l0 & size) == 0;
+                    const u64 x = skeys[l0], y = skeys[h0];
+                    if ((x > y) == up) { skeys[l0] = y; skeys[h0] = x; }
                 }
                 __syncthreads();
             }
-        if (wave != 0) return;
-        // wave 0: chunked greedy walk over the sorted candidates
-        int nsel = 0;
-        for (int c0 = 0; c0 < k && nsel < max_boxes; c0 += 64) {
-            const int i = c0 + lane;
-            const bool valid = i < k;
-            const u64 mykey = valid ? skeys[i] : 0ull;
-            const unsigned idx = valid ? key_index<MODE>(mykey) : 0u;
-            f32x4 box = {0.f, 0.f, 0.f, 0.f};
-            if (valid) box = bx[idx];
-            bool alive = valid;
-            for (int s = 0; s < nsel; ++s)
-                if (alive && suppresses<MODE>(selbox[s], box, iou_thr)) alive = false;
-            u64 mask = 0;                       // bit j: chunk member j (better ranked) suppresses me
-            for (int j = 0; j < 63; ++j) {
-                f32x4 o;
-                o[0] = __shfl(box[0], j); o[1] = __shfl(box[1], j); o[2] = __shfl(box[2], j); o[3] = __shfl(box[3], j);
-                if (j < lane && suppresses<MODE>(o, box, iou_thr)) mask |= 1ull << j;
-            }
-            masks[lane] = mask;
-            const u64 alive_mask = __ballot(alive);
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): masks[] written by this wave only
-            __builtin_amdgcn_wave_barrier();
-            u64 selected = 0;
-            int cnt = nsel;
-            for (int t = 0; t < 64; ++t) {      // suppression scan (wave-uniform)
-                if (((alive_mask >> t) & 1) && cnt < max_boxes && (masks[t] & selected) == 0) {
-                    selected |= 1ull << t;
-                    ++cnt;
+        if (wave == 0) {
+            // chunked greedy walk over the sorted candidates of the round
+            for (int c0 = 0; c0 < cnt && nsel < max_boxes; c0 += 64) {
+                const int i = c0 + lane;
+                const bool valid = i < cnt;
+                const u64 mykey = valid ? skeys[i] : 0ull;
+                const unsigned idx = valid ? key_index<MODE>(mykey) : 0u;
+                f32x4 box = {0.f, 0.f, 0.f, 0.f};
+                if (valid) box = bx[idx];
+                bool alive = valid;
+                for (int sidx = 0; sidx < nsel; ++sidx)
+                    if (alive && suppresses<MODE>(selbox[sidx], box, iou_thr)) alive = false;
+                u64 mask = 0;                       // bit j: chunk member j (better ranked) suppresses me
+                for (int j = 0; j < 63; ++j) {
+                    f32x4 o;
+                    o[0] = __shfl(box[0], j); o[1] = __shfl(box[1], j); o[2] = __shfl(box[2], j); o[3] = __shfl(box[3], j);
+                    if (j < lane && suppresses<MODE>(o, box, iou_thr)) mask |= 1ull << j;
                 }
+                masks[lane] = mask;
+                const u64 alive_mask = __ballot(alive);
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): masks[] written by this wave only
+                __builtin_amdgcn_wave_barrier();
+                u64 selected = 0;
+                int cntsel = nsel;
+                for (int t = 0; t < 64; ++t) {      // suppression scan (wave-uniform)
+                    if (((alive_mask >> t) & 1) && cntsel < max_boxes && (masks[t] & selected) == 0) {
+                        selected |= 1ull << t;
+                        ++cntsel;
+                    }
+                }
+                if ((selected >> lane) & 1) {
+                    const int pos = nsel + __popcll(selected & ((1ull << lane) - 1));
+                    selbox[pos] = box;
+                    out_idx[pos] = (int)idx;
+                    if (out_sc) out_sc[pos] = key_score(mykey);
+                }
+                nsel = cntsel;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
             }
-            if ((selected >> lane) & 1) {
-                const int pos = nsel + __popcll(selected & ((1ull << lane) - 1));
-                selbox[pos] = box;
-                out_idx[pos] = (int)idx;
-                if (out_sc) out_sc[pos] = key_score(mykey);
-            }
-            nsel = cnt;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (lane == 0) sel_count[bc] = nsel;
-        return;
-    }
-
-    // k > kSortCap: best-alive passes (no sort)
-    int nsel = 0;
-    bool have = false;
-    u64 selkey = 0;
-    f32x4 sbox = {0.f, 0.f, 0.f, 0.f};
-    while (true) {
-        u64 best = kDead;
-        for (int i = tid; i < k; i += 256) {
-            const u64 key = keys[i];
-            if (key == kDead) continue;
-            if (have) {
-                if (key == selkey) { keys[i] = kDead; continue; }
-                const f32x4 box = bx[key_index<MODE>(key)];
-                if (suppresses<MODE>(sbox, box, iou_thr)) { keys[i] = kDead; continue; }
-            }
-            best = key < best ? key : best;
-        }
-        for (int d = 32; d > 0; d >>= 1) {
-            const u64 o = __shfl_xor(best, d);
-            best = o < best ? o : best;
-        }
-        if (lane == 0) wbest[wave] = best;
-        __syncthreads();
-        if (tid == 0) {
-            u64 m = wbest[0];
-            for (int w = 1; w < 4; ++w) m = wbest[w] < m ? wbest[w] : m;
-            bcast_key = m;
+            if (lane == 0) s_nsel = nsel;
         }
         __syncthreads();
-        selkey = bcast_key;
-        if (selkey == kDead) break;
-        const unsigned idx = key_index<MODE>(selkey);
-        sbox = bx[idx];
-        have = true;
-        if (tid == 0) {
-            out_idx[nsel] = (int)idx;
-            if (out_sc) out_sc[nsel] = key_score(selkey);
-        }
-        ++nsel;
-        if (nsel >= max_boxes) break;
+        nsel = s_nsel;
+        if (nsel >= max_boxes || hi == kDead) break;      // enough boxes, or that was the last key range
+        lo = hi;
     }
     if (tid == 0) sel_count[bc] = nsel;
 }
