@@ -238,11 +238,13 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
                                                          float iou_thr, const int* __restrict__ cand_count,
                                                          u64* __restrict__ cand_keys, int* __restrict__ sel_count,
                                                          int* __restrict__ sel_idx, float* __restrict__ sel_score) {
-    __shared__ u64 skeys[kSortCap];
-    __shared__ f32x4 selbox[kSelCap];
+    __shared__ u64 skeys[kSortCap];            // 16 KB: the round's keys; before they are gathered, the radix histogram
+    extern __shared__ f32x4 selbox[];          // [max_boxes] selected boxes (dynamic: a small LDS footprint keeps 8
+                                               // workgroups per CU for the usual few candidates per class)
     __shared__ u64 masks[64];
-    __shared__ int hist[4096];
     __shared__ int part[256];
+    int* const hist = (int*)skeys;             // 4096 bins = the same 16 KB; never live together with the keys
+    static_assert(sizeof(u64) * kSortCap >= sizeof(int) * 4096, "histogram must fit the key buffer");
     __shared__ int s_take, s_first, s_cnt, s_nsel;
 
     const int bc = blockIdx.x;                 // b * C + c
@@ -460,7 +462,7 @@ static int nms_run(const float* boxes, const float* scores, int B, int n, int C,
     const unsigned ctiles = (unsigned)((C + kTileC - 1) / kTileC);
     hipLaunchKernelGGL(nms_compact_kernel<MODE>, dim3(tiles, B, ctiles), dim3(256), 0, stream, scores, n, C, st, w.cand_count, w.cand_keys);
     YOLO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(nms_select_kernel<MODE>, dim3((unsigned)(B * C)), dim3(256), 0, stream, boxes, n, C, max_boxes, it,
+    hipLaunchKernelGGL(nms_select_kernel<MODE>, dim3((unsigned)(B * C)), dim3(256), (size_t)max_boxes * 16, stream, boxes, n, C, max_boxes, it,
                        w.cand_count, w.cand_keys, w.sel_count, w.sel_idx, (float*)nullptr);
     YOLO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, stream, boxes, scores, n, C, max_boxes,
@@ -491,7 +493,7 @@ static int post_run(DecodeK k, int B, int max_boxes, float st, float it, float* 
     else
         hipLaunchKernelGGL(fn, dim3(tiles, B), dim3(256), lds, stream, k, st, w.cand_count, w.cand_keys);
     YOLO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(nms_select_kernel<YOLO_NMS_TF>, dim3((unsigned)(B * C)), dim3(256), 0, stream, w.boxes, n, C, max_boxes, it,
+    hipLaunchKernelGGL(nms_select_kernel<YOLO_NMS_TF>, dim3((unsigned)(B * C)), dim3(256), (size_t)max_boxes * 16, stream, w.boxes, n, C, max_boxes, it,
                        w.cand_count, w.cand_keys, w.sel_count, w.sel_idx, w.sel_score);
     YOLO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, stream, w.boxes, (const float*)nullptr, n, C,
