@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--layer-table", default="", help="write the per-layer timing table to this file")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run concurrently on separate streams inside the library "
-                                                         "(YOLO_LANES); 0 = library default (2 from batch 12 up)")
+                                                         "(YOLO_LANES); 0 = library default (2 from batch 12 up, 3 from batch 48 up)")
     ap.add_argument("--h2d", action="store_true", help="also report the rate with the batch copied from pinned host memory "
                                                        "inside every step (extra key, never `value`)")
     args = ap.parse_args()
@@ -161,10 +161,10 @@ def main():
     peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     traffic = TRAFFIC_BYTES_PER_LAUNCH.get((dom_name, B, S))
-    lanes = int(os.environ.get("YOLO_LANES", "0")) or (2 if B >= 12 else 1)
+    lanes = int(os.environ.get("YOLO_LANES", "0")) or (3 if B >= 48 else 2 if B >= 12 else 1)
     roofline = {"bound": "mfma", "kernel": dom_name,
                 "measured": "HIP events around every layer of one launch per layer over the full batch (yolo_net_forward_timed); "
-                            "the timed steps run the same kernels as %d concurrent lane(s) of %d images" % (lanes, B // lanes),
+                            "the timed steps run the same kernels as %d concurrent lane(s) of ~%d images" % (lanes, B // lanes),
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches_per_step": dom["launches"],
                 "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),

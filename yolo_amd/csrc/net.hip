@@ -505,12 +505,13 @@ extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->
 // GPU: the partly filled last round of workgroups of one launch (e.g. 676 tiles on 512 slots) and the drain / fill
 // between dependent launches are covered by the other lane's kernels.  Results do not depend on the split: every
 // output element is accumulated in the same order whatever tile or batch it is part of.
-// Default: 2 lanes from batch 12 up.  YOLO_LANES=<n> in the environment (read per call) sets the number of lanes;
+// Default: 2 lanes from batch 12 up, 3 from batch 48 up.  YOLO_LANES=<n> in the environment (read per call) sets the number of lanes;
 // 1 = one launch per layer for the whole batch.
 constexpr int MAX_LANES = 4;
 static int lane_count(int B) {
     const char* e = getenv("YOLO_LANES");
-    int n = e ? atoi(e) : (B >= 12 ? 2 : 1);      // measured (scripts/lanes.py): +5..8 % from batch 12 up, a loss below 8
+    int n = e ? atoi(e) : (B >= 48 ? 3 : B >= 12 ? 2 : 1);   // measured (scripts/lanes.py): +5..8 % from batch 12 up, a loss below 8;
+                                                             // a third lane adds 0.2..1 % at batch 64
     if (n < 1) n = 1;
     if (n > MAX_LANES) n = MAX_LANES;
     return n < B ? n : B;
