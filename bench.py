@@ -26,11 +26,11 @@ F32_PEAK_TFLOPS = 157.3
 # section 5): 2 x FETCH_SIZE + WRITE_SIZE averaged over the launches of one bench step (FETCH_SIZE doubled as
 # MI355X_MICROARCH.md "HBM" prescribes for gfx950).  Keyed by (kernel, batch, size); None when not measured.
 TRAFFIC_BYTES_PER_LAUNCH = {
-    # profiles/r1_bench_pmc_traffic_v4_lanes1.txt (one launch per layer over the full batch, as the roofline is measured):
-    # halo kernel, two patch buffers: fetch 138.92 MB (2 x FETCH_SIZE) + write 35.69 MB
-    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, false, 32>", 64, 416): 174.60e6,
-    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, true, 32>", 64, 416): 245.28e6,
-    ("yolo::conv_igemm_kernel<true, 128, 128, 4, 2, 2>", 64, 416): 119.49e6,
+    # profiles/r1_bench_pmc_traffic_v5_lanes1.txt (one launch per layer over the full batch, as the roofline is measured):
+    # halo kernel, two patch buffers: fetch 138.70 MB (2 x FETCH_SIZE) + write 35.69 MB
+    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, false, 32>", 64, 416): 174.39e6,
+    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, true, 32>", 64, 416): 245.34e6,
+    ("yolo::conv_igemm_kernel<true, 128, 128, 4, 2, 2>", 64, 416): 119.59e6,
 }
 
 
