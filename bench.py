@@ -223,12 +223,25 @@ def main():
 
         dth = timed(lambda: net.detect(host.to("cuda", non_blocking=True), 50, 0.5, 0.5))
         dtu = timed(lambda: net.detect(preprocess(host_u8.to("cuda", non_blocking=True), (S, S)), 50, 0.5, 0.5))
+        from yolo_amd.pipeline import DetectPipeline
+        pipe = DetectPipeline(net, (S, S), 50, 0.5, 0.5)
+        for _ in pipe.run([host_u8] * 3):
+            pass
+        barrier()
+        t0 = time.perf_counter()
+        for _ in pipe.run([host_u8] * args.steps):
+            pass
+        barrier()
+        dtp = (time.perf_counter() - t0) / args.steps
         h2d = {"images_per_sec": round(B / dth, 2), "ms_per_step": round(dth * 1e3, 4),
                "what": "same step with the %d MB f32 batch copied from pinned host memory each step (serial copy + compute)"
                        % (images.numel() * 4 // 1000000),
                "uint8_upload": {"images_per_sec": round(B / dtu, 2), "ms_per_step": round(dtu * 1e3, 4),
                                 "what": "%d MB uint8 BGR batch copied from pinned host memory, then yolo_preprocess "
-                                        "(resize / BGR2RGB / /255 on the GPU) + the step" % (host_u8.numel() // 1000000)}}
+                                        "(resize / BGR2RGB / /255 on the GPU) + the step" % (host_u8.numel() // 1000000)},
+               "uint8_pipelined": {"images_per_sec": round(B / dtp, 2), "ms_per_step": round(dtp * 1e3, 4),
+                                   "what": "the same with yolo_amd.pipeline.DetectPipeline: the copy of batch i+1 runs on a copy "
+                                           "stream under preprocess + detect of batch i"}}
 
     if rank == 0:
         res = {

@@ -113,3 +113,33 @@ def test_single_image_driver_rescales_boxes(torch_cuda, weight_stream):
     single = detect_image(net, frames[1], (96, 64), 30, 0.01, 0.5)
     assert all(np.array_equal(a, b) for a, b in zip(single, res[1]))
     assert total > 0
+
+
+@pytest.mark.gpu
+def test_detect_pipeline_equals_sequential(torch_cuda, weight_stream):
+    """DetectPipeline (H2D copy of batch i+1 under the compute of batch i) returns what preprocess + detect return."""
+    import torch
+    from yolo_amd.model import yolov3
+    from yolo_amd.pipeline import DetectPipeline
+    from yolo_amd.preprocess import preprocess
+    from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
+    net = yolov3(80, DEFAULT_ANCHORS, dtype="bf16").load_weight_stream(weight_stream)
+    rng = np.random.default_rng(71)
+    batches = [rng.integers(0, 256, (3, 90, 120, 3), dtype=np.uint8) for _ in range(5)]
+    batches[3] = torch.from_numpy(batches[3]).pin_memory()           # a caller-pinned batch skips the staging copy
+    pipe = DetectPipeline(net, (96, 64), 20, 0.01, 0.45)
+    got = [[t.clone() for t in out] for out in pipe.run(batches)]
+    assert len(got) == 5
+    total = 0
+    for frames, out in zip(batches, got):
+        ref = net.detect(preprocess(frames, (96, 64)), 20, 0.01, 0.45)
+        cnt = ref[4].cpu().numpy()
+        total += int(cnt.sum())
+        assert torch.equal(out[4], ref[4])
+        for b in range(3):
+            for j in range(4):
+                assert torch.equal(out[j][b, :cnt[b]], ref[j][b, :cnt[b]])
+    assert total > 0
+    assert list(pipe.run([])) == []
+    with pytest.raises(ValueError):
+        list(pipe.run([np.zeros((2, 8, 8, 3), np.float32)]))
