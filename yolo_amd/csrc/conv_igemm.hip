@@ -1004,6 +1004,13 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
     int cfg = forced ? atoi(forced) : -1;
     const int sz = BF16 ? 2 : 4;
     const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32 && !k.reorg;
+    if (cfg >= 43 && cfg <= 46) {                               // ping-pong tile on the small (43, 44) / large (45, 46) maps only
+        if constexpr (BF16) {
+            if (halo_ok && k.Cout % 256 == 0 && (cfg <= 44 ? k.W <= 32 : k.W > 32) && 256 + 2 * k.W + 2 <= 504)
+                return (cfg & 1) ? launch_p8<4>(k, stream) : launch_p8<3>(k, stream);
+        }
+        cfg = -1;
+    }
     if (cfg >= 20 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
