@@ -589,3 +589,41 @@ def test_nms_many_candidates_with_equal_scores(torch_cuda, oracle, mode):
         for c in range(C):
             got = nms_utils.py_nms(boxes, scores[:, c], max_boxes=40, iou_thresh=0.3)
             assert got == [int(v) for v in oracle.py_nms(boxes, scores[:, c], 40, 0.3)], c
+
+
+def test_detect_batch64_416_properties(net_bf16, oracle):
+    """BASELINE config 2 at full size (batch 64, 416 x 416, bf16, thresholds 50 / 0.5 / 0.5), through size-independent
+    properties: images are independent (any sub-batch gives the same rows, bit for bit), and every image's detections
+    are a fixed point of the oracle's NMS: per class sorted by score, all >= score_thresh, no kept pair above the IoU
+    threshold, and re-running the oracle NMS on the kept boxes keeps them all."""
+    import torch
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.random((64, 416, 416, 3), dtype=np.float32)).cuda()
+    ob, osc, ol, oi, oc = [t.clone() for t in net_bf16.detect(x, 50, 0.5, 0.5)]
+    cnt = oc.cpu().numpy()
+    assert cnt.sum() > 1000 and cnt.max() <= 80 * 50
+    for lo, hi in ((5, 6), (40, 43), (63, 64)):
+        sb, ss, sl, si, sc = net_bf16.detect(x[lo:hi], 50, 0.5, 0.5)
+        assert torch.equal(sc, oc[lo:hi])
+        for j in range(hi - lo):
+            m = int(cnt[lo + j])
+            for a, b in ((sb, ob), (ss, osc), (sl, ol), (si, oi)):
+                assert torch.equal(a[j, :m], b[lo + j, :m])
+    fms = net_bf16.forward(x)
+    boxes, _, _, scores = net_bf16.predict(fms, return_scores=True)
+    for b in (0, 17, 63):
+        m = int(cnt[b])
+        kb, ks, kl, ki = [t[b, :m].cpu().numpy() for t in (ob, osc, ol, oi)]
+        assert np.all(ks >= np.float32(0.5))
+        assert np.array_equal(kb, boxes[b].cpu().numpy()[ki])                       # rows are the decoded boxes they index
+        assert np.array_equal(ks, scores[b].cpu().numpy()[ki, kl])
+        assert np.all(np.diff(kl) >= 0)                                             # classes ascending (nms_utils.py:23)
+        for c in np.unique(kl):
+            sel = kl == c
+            s_c, b_c = ks[sel], kb[sel]
+            assert np.all(s_c[:-1] >= s_c[1:]) and len(s_c) <= 50
+            again = oracle.tf_non_max_suppression(b_c, s_c, 50, 0.5)
+            assert np.array_equal(again, np.arange(len(s_c)))                       # idempotent: nothing kept suppresses anything kept
+        # and the whole image equals the oracle's per-class NMS run on the SAME decoded boxes / scores
+        _, _, rl, ri = oracle.gpu_nms(boxes[b].cpu().numpy(), scores[b].cpu().numpy(), 80, 50, 0.5, 0.5, return_indices=True)
+        assert np.array_equal(ki, ri) and np.array_equal(kl, rl)
