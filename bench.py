@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=6)
+    ap.add_argument("--cpu-images", type=int, default=32, help="images of the CPU baseline sample (about 10 s of host work)")
     ap.add_argument("--layer-table", default="", help="write the per-layer timing table to this file")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run concurrently on separate streams inside the library "
                                                          "(YOLO_LANES); 0 = library default (2 from batch 12 up, 3 from batch 48 up)")
