@@ -30,7 +30,7 @@ for idx in [int(x) for x in a.only.split(",")]:
     L.yolo_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert L.yolo_debug_read_stamps(buf.ctypes.data, 512) == 0
     st = buf.reshape(64, 8).astype(np.float64)
-    st = st[st[:, 7] > 0]
+    st = st[st[:, 4] > 0]
     nsteps = (k * k * cin * 2 + 127) // 128
     print("layer %d cfg %s: %.4f ms, %d sampled blocks, %d K-steps" % (idx, a.cfg or "default", ms.value, len(st), nsteps))
     if a.cfg in ("22", "23"):

@@ -14,7 +14,9 @@
 //   * math: v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32), f32 accumulate.
 //   * double-buffered LDS, one barrier per 128-byte K-step.
 //   * epilogue through LDS so that stores are 16 B per lane, channel-contiguous.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "common.h"
 
@@ -61,7 +63,9 @@ struct ConvK {
 // stores, no LDS - was measured 15-25 % SLOWER per layer: 32 partial lines per store instruction.)
 // MS: MFMA tile edge (32: v_mfma_f32_32x32x16_bf16 / 32x32x2_f32, 16 registers per lane; 16: v_mfma_f32_16x16x32_bf16,
 // 4 registers per lane).  fr = lane % MS (column), fh = lane / MS; register r holds row (r&3) + 8*(r>>2) + 4*fh.
-template <bool BF16, int BM, int BN, int TM, int TN, int NT, int MS = 32, typename AccT = f32x16>
+// PASSES > 1: the staging buffer holds BM / PASSES rows at a time (the waves that own those rows write, everybody stores),
+// so that a 256-row tile's epilogue fits the LDS share of two workgroups per CU.
+template <bool BF16, int BM, int BN, int TM, int TN, int NT, int MS = 32, typename AccT = f32x16, int PASSES = 1>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN], char* lds, int m0, int n0,
                                               int wm0, int wn0, int tid, int fr, int fh
 #ifdef YOLO_CONV_STAMPS
@@ -70,9 +74,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
                                               ) {
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int LDC = BN + 4;
+    constexpr int BMP = BM / PASSES;            // rows staged per pass
+    static_assert(BM % PASSES == 0 && BMP % (TM * MS) == 0, "epilogue passes must be whole wave row blocks");
     float* ct = (float*)lds;
     __syncthreads();                      // every wave is done reading the staging buffers
     STAMP(5);
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+    const int r0 = pass * BMP;                  // first tile row of this pass
+    if (PASSES > 1 && pass > 0) __syncthreads();   // the previous pass's staging has been read
     auto to_lds = [&](auto mode) {              // activation mode as a compile-time constant: no branch per element
         constexpr int MODE = decltype(mode)::value;
 #pragma unroll
@@ -83,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < MS * MS / 64; ++r) {
-                    const int row = wm0 + i * MS + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int row = wm0 - r0 + i * MS + (r & 3) + 8 * (r >> 2) + 4 * fh;
                     float v = acc[i][j][r] + bv;
                     if constexpr (MODE == 1) v = leaky_v3(v);
                     else if constexpr (MODE == 2) v = __builtin_fmaxf(0.1f * v, v);
@@ -91,9 +102,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
                 }
         }
     };
-    if (p.leaky == 1) to_lds(std::integral_constant<int, 1>{});
-    else if (p.leaky == 2) to_lds(std::integral_constant<int, 2>{});
-    else to_lds(std::integral_constant<int, 0>{});
+    if (PASSES == 1 || (wm0 >= r0 && wm0 < r0 + BMP)) {
+        if (p.leaky == 1) to_lds(std::integral_constant<int, 1>{});
+        else if (p.leaky == 2) to_lds(std::integral_constant<int, 2>{});
+        else to_lds(std::integral_constant<int, 0>{});
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     STAMP(6);
     __syncthreads();
@@ -102,25 +115,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
     if (p.out_f32) {
         // detection heads: Cout = 3*(5+C) is not a multiple of 8 -> scalar f32 stores, channel-coalesced
         float* outf = (float*)p.out;
-        for (int idx = tid; idx < BM * BN; idx += NT) {
+        for (int idx = tid; idx < BMP * BN; idx += NT) {
             const int row = idx / BN, col = idx - row * BN;
-            const int m = m0 + row, n = n0 + col;
+            const int m = m0 + r0 + row, n = n0 + col;
             if (m < p.M && n < p.Cout) outf[(long long)m * p.out_ld + p.out_coff + n] = ct[row * LDC + col];
         }
-        return;
+        continue;
     }
 
     constexpr int CH = BN / 8;
-    constexpr int ITERS = BM * CH / NT;
-    static_assert(BM * CH % NT == 0, "epilogue geometry");
-    const int HoWo = p.Ho * p.Wo;
+    constexpr int ITERS = BMP * CH / NT;
+    static_assert(BMP * CH % NT == 0, "epilogue geometry");
     u32x4 rres[ITERS][BF16 ? 1 : 2];
     if (p.res) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = tid + it * NT;
             const int row = idx / CH, ch = idx - row * CH;
-            const int m = m0 + row, n = n0 + ch * 8;
+            const int m = m0 + r0 + row, n = n0 + ch * 8;
             const bool ok = m < p.M && n < p.Cout;
             const char* rp = p.res + ((long long)(ok ? m : 0) * p.res_ld + p.res_coff + (ok ? n : 0)) * SZ;
             rres[it][0] = *(const u32x4*)rp;
@@ -131,7 +143,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
         const int row = idx / CH, ch = idx - row * CH;
-        const int m = m0 + row;
+        const int m = m0 + r0 + row;
         int n = n0 + ch * 8;
         if (m >= p.M || n >= p.Cout) continue;
         f32x4 v0 = *(const f32x4*)(ct + row * LDC + ch * 8);
@@ -143,9 +155,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
             } else {
-                const f32x4 r0 = __builtin_bit_cast(f32x4, rres[it][0]), r1 = __builtin_bit_cast(f32x4, rres[it][1]);
+                const f32x4 r0v = __builtin_bit_cast(f32x4, rres[it][0]), r1v = __builtin_bit_cast(f32x4, rres[it][1]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                for (int e = 0; e < 4; ++e) { v[e] += r0v[e]; v[4 + e] += r1v[e]; }
             }
         }
         long long pix[4];
@@ -181,6 +193,97 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
                 *(f32x4*)(op + 16) = o1;
             }
         }
+    }
+    }   // pass
+}
+
+// ---- wave-private epilogue (plain or residual stores only): every wave transposes its own accumulator tile through a
+// private LDS region, 32 pixel rows at a time, and stores it itself - one workgroup barrier (the staging buffers are
+// free) instead of two per pass, accumulator registers die half a tile at a time, and a wave's stores overlap the
+// other waves' transposes.  Same arithmetic as conv_epilogue: (acc + bias) -> activation -> + residual -> bf16.
+template <bool BF16, int TM, int TN, int MS, typename AccT>
+__device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[TM][TN], char* lds, int m0, int n0,
+                                                   int wm0, int wn0, int wave, int lane, int fr, int fh) {
+    constexpr int SZ = BF16 ? 2 : 4;
+    constexpr int WN = TN * MS;                 // channels of the wave tile
+    constexpr int LDW = WN + 4;
+    constexpr int SUB = 32;                     // rows per sub-pass
+    constexpr int NSUB = TM * MS / SUB;
+    constexpr int IPS = SUB / MS;               // accumulator row tiles per sub-pass
+    constexpr int CH = WN / 8;
+    constexpr int ITERS = SUB * CH / 64;
+    static_assert(TM * MS % SUB == 0 && SUB % MS == 0 && (SUB * CH) % 64 == 0, "wave epilogue geometry");
+    float* ct = (float*)lds + wave * (SUB * LDW);
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = p.bias[n0 + wn0 + j * MS + fr];
+    __syncthreads();                            // every wave is done reading the staging buffers
+    const int leaky = p.leaky;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        const int mrow0 = m0 + wm0 + s * SUB;
+        u32x4 rres[ITERS][BF16 ? 1 : 2];
+        if (p.res) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = lane + it * 64;
+                const int row = idx / CH, ch = idx - row * CH;
+                const int m = mrow0 + row, n = n0 + wn0 + ch * 8;
+                const bool ok = m < p.M && n < p.Cout;
+                const char* rp = p.res + ((long long)(ok ? m : 0) * p.res_ld + p.res_coff + (ok ? n : 0)) * SZ;
+                rres[it][0] = *(const u32x4*)rp;
+                if constexpr (!BF16) rres[it][1] = *(const u32x4*)(rp + 16);
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+            const int i = s * IPS + ii;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < MS * MS / 64; ++r) {
+                    const int row = ii * MS + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    float v = acc[i][j][r] + bv[j];
+                    v = leaky == 1 ? leaky_v3(v) : leaky == 2 ? __builtin_fmaxf(0.1f * v, v) : v;
+                    ct[row * LDW + j * MS + fr] = v;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = lane + it * 64;
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = mrow0 + row, n = n0 + wn0 + ch * 8;
+            const f32x4 v0 = *(const f32x4*)(ct + row * LDW + ch * 8);
+            const f32x4 v1 = *(const f32x4*)(ct + row * LDW + ch * 8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (p.res) {
+                if constexpr (BF16) {
+                    const bf16x8 rv = __builtin_bit_cast(bf16x8, rres[it][0]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                } else {
+                    const f32x4 r0v = __builtin_bit_cast(f32x4, rres[it][0]), r1v = __builtin_bit_cast(f32x4, rres[it][1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0v[e]; v[4 + e] += r1v[e]; }
+                }
+            }
+            if (m < p.M && n < p.Cout) {
+                char* op = p.out + ((long long)m * p.out_ld + p.out_coff + n) * SZ;
+                if constexpr (BF16) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                    *(bf16x8*)op = o;
+                } else {
+                    *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(op + 16) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging rows have been read before the next sub-pass rewrites them
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -423,8 +526,9 @@ extern "C" int yolo_debug_read_stamps(unsigned long long* host, int n) {
 // one (one exposed load latency per chunk) - half the patch LDS, so that two workgroups fit a CU at larger W.
 // MS = 16 (bf16 only): the same wave tile out of v_mfma_f32_16x16x32_bf16 - same LDS reads and MFMA cycles per FLOP;
 // the chip holds a higher clock on that shape (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB, int MS>
-__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(ConvK p, int prows) {
+// EPASS: epilogue staging passes (conv_epilogue); MINW: waves per SIMD the register allocation must allow.
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB, int MS, int EPASS = 1, int MINW = 1>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_kernel(ConvK p, int prows) {
     static_assert(MS == 32 || (MS == 16 && BF16), "MFMA shape");
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int NW = WARPS_M * WARPS_N;
@@ -613,11 +717,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv3x3_halo_kernel(Co
 #endif
         }
     }
-    #ifdef YOLO_CONV_STAMPS
-    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
+    if constexpr (EPASS == 0) {
+        STAMP(5);
+        conv_epilogue_wave<BF16, TM, TN, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, wave, lane, fr, fh);
+        STAMP(6);
+    } else {
+#ifdef YOLO_CONV_STAMPS
+    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
 #else
-    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
+    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
 #endif
+    }
 #ifdef YOLO_CONV_STAMPS
     {
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();
@@ -945,18 +1055,18 @@ static int launch_p8(const ConvK& k, hipStream_t stream) {
     return YOLO_OK;
 }
 
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32>
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32, int EPASS = 1, int MINW = 1>
 static int launch_halo(const ConvK& k, hipStream_t stream) {
-    if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32>(k, stream);
+    if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32, EPASS, MINW>(k, stream);
     else {
     const int prows = (int)align_up((size_t)(BM + 2 * k.W + 2), 8);
     const int nchunks = k.Cin * (BF16 ? 2 : 4) / 128;
     const int loop_bytes = ((nchunks > 1 && !SPB) ? 2 : 1) * prows * 128 + 2 * BN * 128 + 128;
-    constexpr int epi_bytes = BM * (BN + 4) * 4;
+    constexpr int epi_bytes = EPASS == 0 ? WARPS_M * WARPS_N * 32 * (BN / WARPS_N + 4) * 4 : BM / (EPASS ? EPASS : 1) * (BN + 4) * 4;
     const int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
     YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 halo: W=%d needs %d bytes of LDS", k.W, lds_bytes);
     YOLO_REQUIRE((long long)k.M * k.in_ld * (BF16 ? 2 : 4) < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 halo: input larger than 4 GiB");
-    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB, MS>;
+    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB, MS, EPASS, MINW>;
     static bool attr_done[16] = {false};
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
@@ -967,7 +1077,7 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS);
+    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS, EPASS, MINW);
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
@@ -1004,12 +1114,28 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
     int cfg = forced ? atoi(forced) : -1;
     const int sz = BF16 ? 2 : 4;
     const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32 && !k.reorg;
+    if (const char* hm = getenv("YOLO_HALO_CFG")) {             // experiments: "<W>=<cfg>,..." for the 3x3 stride-1 layers of width W
+        if (halo_ok && cfg < 0)
+            for (const char* q = hm; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+                int w = 0, c = 0;
+                if (sscanf(q, "%d=%d", &w, &c) == 2 && w == k.W) { cfg = c; break; }
+            }
+    }
     if (cfg >= 43 && cfg <= 46) {                               // ping-pong tile on the small (43, 44) / large (45, 46) maps only
         if constexpr (BF16) {
             if (halo_ok && k.Cout % 256 == 0 && (cfg <= 44 ? k.W <= 32 : k.W > 32) && 256 + 2 * k.W + 2 <= 504)
                 return (cfg & 1) ? launch_p8<4>(k, stream) : launch_p8<3>(k, stream);
         }
         cfg = -1;
+    }
+    if (cfg >= 53 && cfg <= 56) {                               // the 256 x 128 two-workgroup tile on the small maps only
+        if (halo_ok && k.W <= 32) cfg = cfg == 53 ? 50 : cfg == 54 ? 51 : cfg == 55 ? 60 : 61;
+        else cfg = -1;
+    }
+    if (cfg == 67) cfg = !halo_ok ? -1 : k.W <= 32 ? 62 : 63;    // the shipped tiling with the wave-private epilogue
+    if (cfg >= 65 && cfg <= 66) {                               // ... and up to 52 x 52
+        if (halo_ok && k.W <= 52) cfg = cfg == 65 ? 60 : 61;
+        else cfg = -1;
     }
     if (cfg >= 20 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
@@ -1022,10 +1148,14 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         const int patch_bufs = k.Cin * sz > 128 ? 2 : 1;
         if (k.Cout <= 32) cfg = 10;
         else if (k.Cout <= 64) cfg = k.ksize == 1 ? 14 : 12;
+        // 256 x 128 tile, 8 waves of 64 x 64 on 16x16x32 MFMAs, wave-private epilogue, two workgroups per CU (round 2:
+        // +9 % end to end over 24 / 28 on the 13x13 .. 52x52 maps)
+        else if (halo_ok && BF16 && k.W <= 16) cfg = 68;     // 13x13: 128 x 128 tiles of 4 such waves fill the CUs more evenly
+        else if (halo_ok && BF16 && k.W <= 52) cfg = 61;
         else if (halo_ok && k.W <= 32) cfg = 24;
         // larger maps: a single patch buffer keeps two 128x128 workgroups per CU (measured 10 % faster than the
         // 16-wave 256x128 workgroup at 52x52, 7 % at 104x104)
-        else if (halo_ok && (int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 80 * 1024) cfg = 28;
+        else if (halo_ok && (int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 80 * 1024) cfg = BF16 ? 69 : 28;
         else if (halo_ok && patch_bufs * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 26;
         else cfg = 5;
     }
@@ -1044,6 +1174,18 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 26: return launch_halo<BF16, 256, 128, 8, 2>(k, stream);      // 16 waves, 1 block/CU
         case 27: return launch_halo<BF16, 256, 128, 4, 4>(k, stream);
         case 28: return launch_halo<BF16, 128, 128, 4, 2, true>(k, stream);   // single patch buffer: 2 blocks/CU up to W ~ 60
+        // 256 x 128 tile, 8 waves of 64 x 64 (half the LDS fragment reads and LDS-DMA pieces per MFMA of 24 / 28), single
+        // patch buffer + two-pass epilogue staging: <= 80 KB of LDS up to W = 52 and <= 128 VGPRs, so two workgroups per CU
+        case 50: return launch_halo<BF16, 256, 128, 4, 2, true, 32, 2, 4>(k, stream);
+        case 51: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 2, 4>(k, stream);   // the same out of 16x16x32 MFMAs
+        case 52: return launch_halo<BF16, 256, 128, 4, 2, false, 32, 2, 2>(k, stream);  // two patch buffers, one workgroup per CU
+        case 60: return launch_halo<BF16, 256, 128, 4, 2, true, 32, 0, 4>(k, stream);   // 50 / 51 with the wave-private epilogue
+        case 61: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 0, 4>(k, stream);
+        case 62: return launch_halo<BF16, 128, 128, 4, 2, false, 32, 0, 1>(k, stream);  // the shipped 24 / 28 with the wave-private epilogue
+        case 63: return launch_halo<BF16, 128, 128, 4, 2, true, 32, 0, 1>(k, stream);
+        case 64: return launch_halo<BF16, 128, 128, 2, 2, true, 32, 0, 2>(k, stream);   // 4 waves of 64 x 64, up to four workgroups per CU
+        case 68: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2>(k, stream);
+        case 69: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 0, 1>(k, stream);   // 28 on 16x16x32 with the wave-private epilogue
         case 40: case 41: case 42:                                          // 256 / 192 / 128 x 256 ping-pong tile, bf16 only
             if constexpr (BF16) {
                 if (k.Cout % 256 == 0) return cfg == 40 ? launch_p8<4>(k, stream) : cfg == 41 ? launch_p8<3>(k, stream) : launch_p8<2>(k, stream);

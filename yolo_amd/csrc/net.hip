@@ -507,7 +507,7 @@ extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->
 // output element is accumulated in the same order whatever tile or batch it is part of.
 // Default: 2 lanes from batch 12 up, 3 from batch 48 up.  YOLO_LANES=<n> in the environment (read per call) sets the number of lanes;
 // 1 = one launch per layer for the whole batch.
-constexpr int MAX_LANES = 4;
+constexpr int MAX_LANES = 8;
 static int lane_count(int B) {
     const char* e = getenv("YOLO_LANES");
     int n = e ? atoi(e) : (B >= 48 ? 3 : B >= 12 ? 2 : 1);   // measured (scripts/lanes.py): +5..8 % from batch 12 up, a loss below 8;
