@@ -122,6 +122,19 @@ int yolo_nms(const float* boxes, const float* scores, int B, int n, int class_nu
              int32_t* out_labels, int32_t* out_index, int32_t* out_counts, void* workspace,
              size_t workspace_bytes, void* stream);
 
+/* yolo_nms for callers that cannot allocate device memory or pass a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, results and
+ * error codes as yolo_nms without `workspace`: the candidate / selection arrays live in a YOLO_NMS_STATIC_BYTES
+ * (16 MiB) device array inside the library, of which every GPU the library runs on holds its own copy until the
+ * process ends.  Sizes whose yolo_nms_workspace_bytes exceeds YOLO_NMS_STATIC_BYTES (about B * n * class_num > 2 M,
+ * e.g. more than one 608 x 608 image of 80 classes) are refused with YOLO_ERR_UNSUPPORTED.  Calls no hipMalloc /
+ * hipFree.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
+ * threads) race; serialise them. */
+#define YOLO_NMS_STATIC_BYTES ((size_t)16 << 20)
+int yolo_nms_static(const float* boxes, const float* scores, int B, int n, int class_num, int max_boxes,
+                    float score_thresh, float iou_thresh, int mode, float* out_boxes, float* out_scores,
+                    int32_t* out_labels, int32_t* out_index, int32_t* out_counts, void* stream);
+
 /* ---- the post-processing chain of the driver in ONE call: replaces predict (yolo_v3/model.py:110-153), the
  * caller's pred_confs * pred_probs (yolo_v3/test_single_image.py:38) and gpu_nms (yolo_v3/utils/nms_utils.py:7-37),
  * applied to each of the B images independently.  Decode, score product and the score mask run as one pass over

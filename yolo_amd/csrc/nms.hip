@@ -18,6 +18,7 @@
 //                    2048 candidates, best first, cut out by a radix histogram of the keys; stops as soon as
 //                    max_boxes boxes are selected (normally inside the first range).
 //  3. nms_gather  : per image, prefix over class counts -> class-ordered dense output rows.
+#include <mutex>
 #include "decode_common.h"
 
 namespace yolo {
@@ -523,6 +524,58 @@ extern "C" int yolo_nms(const float* boxes, const float* scores, int B, int n, i
     const NmsWs w = nms_layout(workspace, B, n, class_num, max_boxes);
     YOLO_REQUIRE(workspace_bytes >= w.total, YOLO_ERR_WORKSPACE, "nms: workspace %zu < %zu bytes", workspace_bytes, w.total);
     YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "nms: workspace must be 256-byte aligned");
+    if (mode == YOLO_NMS_TF)
+        return nms_run<YOLO_NMS_TF>(boxes, scores, B, n, class_num, max_boxes, score_thresh, iou_thresh, out_boxes, out_scores,
+                                    out_labels, out_index, out_counts, w, (hipStream_t)stream);
+    return nms_run<YOLO_NMS_PY>(boxes, scores, B, n, class_num, max_boxes, score_thresh, iou_thresh, out_boxes, out_scores,
+                                out_labels, out_index, out_counts, w, (hipStream_t)stream);
+}
+
+// ---- yolo_nms for callers that cannot allocate -----------------------------------------------------------------
+// The candidate / selection arrays of nms_layout live in a file-scope device array instead of a caller workspace.
+// Every GPU the library runs on holds its own copy at its own address; `scratch` itself is only the host-side
+// stand-in of the symbol, so host code uses the per-device address from hipGetSymbolAddress, never the name.
+namespace yolo {
+constexpr size_t kStaticScratchBytes = YOLO_NMS_STATIC_BYTES;      // 16 MiB: one 416 or 608 image with 80 classes, or
+                                                              // any B * n * class_num * 8 + small change below it
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static void* g_scratch_ptr[64] = {nullptr};
+static std::mutex g_scratch_mu;
+
+static int static_scratch(void** out) {
+    int dev = 0;
+    YOLO_HIP_CHECK(hipGetDevice(&dev));
+    YOLO_REQUIRE(dev >= 0 && dev < 64, YOLO_ERR_UNSUPPORTED, "nms_static: device ordinal %d not below 64", dev);
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {                                // once per device, with that device current
+        void* ptr = nullptr;
+        YOLO_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        YOLO_REQUIRE(ptr != nullptr && ((uintptr_t)ptr & 255) == 0, YOLO_ERR_HIP, "nms_static: bad scratch address %p", ptr);
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return YOLO_OK;
+}
+}  // namespace yolo
+
+extern "C" int yolo_nms_static(const float* boxes, const float* scores, int B, int n, int class_num, int max_boxes,
+                               float score_thresh, float iou_thresh, int mode, float* out_boxes, float* out_scores,
+                               int32_t* out_labels, int32_t* out_index, int32_t* out_counts, void* stream) {
+    using namespace yolo;
+    YOLO_REQUIRE(boxes && scores && out_boxes && out_scores && out_labels && out_counts, YOLO_ERR_ARG, "nms_static: null pointer");
+    YOLO_REQUIRE(B > 0 && n > 0 && class_num > 0 && max_boxes > 0, YOLO_ERR_ARG, "nms_static: non-positive size");
+    YOLO_REQUIRE(max_boxes <= kSelCap, YOLO_ERR_UNSUPPORTED, "nms_static: max_boxes %d > %d", max_boxes, kSelCap);
+    YOLO_REQUIRE(class_num <= 4096 && B <= 65535, YOLO_ERR_UNSUPPORTED, "nms_static: class_num/B out of range");
+    YOLO_REQUIRE((long long)B * class_num < (1ll << 31) && (long long)B * n < (1ll << 31), YOLO_ERR_SHAPE, "nms_static: problem too large");
+    YOLO_REQUIRE(mode == YOLO_NMS_TF || mode == YOLO_NMS_PY, YOLO_ERR_ARG, "nms_static: bad mode %d", mode);
+    const size_t need = nms_layout(nullptr, B, n, class_num, max_boxes).total;
+    YOLO_REQUIRE(need <= kStaticScratchBytes, YOLO_ERR_UNSUPPORTED,
+                 "nms_static: B=%d n=%d class_num=%d max_boxes=%d needs %zu bytes of scratch, the built-in buffer holds %zu; "
+                 "use yolo_nms with a workspace", B, n, class_num, max_boxes, need, kStaticScratchBytes);
+    void* ptr = nullptr;
+    const int rc = static_scratch(&ptr);
+    if (rc != YOLO_OK) return rc;
+    const NmsWs w = nms_layout(ptr, B, n, class_num, max_boxes);     // cand_count is cleared per call by nms_run
     if (mode == YOLO_NMS_TF)
         return nms_run<YOLO_NMS_TF>(boxes, scores, B, n, class_num, max_boxes, score_thresh, iou_thresh, out_boxes, out_scores,
                                     out_labels, out_index, out_counts, w, (hipStream_t)stream);
