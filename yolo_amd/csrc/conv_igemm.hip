@@ -207,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[T
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int WN = TN * MS;                 // channels of the wave tile
     constexpr int LDW = WN + 4;
-    constexpr int SUB = 32;                     // rows per sub-pass
+    constexpr int SUB = (TM * MS) % 32 == 0 ? 32 : 16;   // rows per sub-pass
     constexpr int NSUB = TM * MS / SUB;
     constexpr int IPS = SUB / MS;               // accumulator row tiles per sub-pass
     constexpr int CH = WN / 8;
@@ -287,13 +287,19 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[T
     }
 }
 
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES>
-__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_igemm_kernel(ConvK p) {
+// MS: MFMA tile edge (32, or 16 = v_mfma_f32_16x16x32_bf16, bf16 only); EPASS = 0: wave-private epilogue (plain / residual
+// stores only - the host never picks it for upsample / reorg / f32-head layers); MINW: waves per SIMD to allocate registers for.
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int MS = 32, int EPASS = 1, int MINW = 1>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kernel(ConvK p) {
+    static_assert(MS == 32 || (MS == 16 && BF16), "MFMA shape");
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int NT = 64 * NW;
-    constexpr int TM = BM / WARPS_M / 32;
-    constexpr int TN = BN / WARPS_N / 32;
+    constexpr int TM = BM / WARPS_M / MS;
+    constexpr int TN = BN / WARPS_N / MS;
+    constexpr int KK = MS / 8;
+    constexpr int KSH = MS == 32 ? 5 : 6;
+    typedef typename std::conditional<MS == 32, f32x16, f32x4>::type AccT;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
     constexpr int BUF_BYTES = A_BYTES + B_BYTES;
@@ -384,29 +390,29 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_igemm_kernel(Conv
 
     // ---- fragment addressing ---------------------------------------------------------------
     const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
-    const int wm0 = wm * (TM * 32), wn0 = wn * (TN * 32);
-    const int fr = lane & 31, fh = lane >> 5;
-    int a_row_off[TM], a_sw[TM], b_row_off[TN], b_sw[TN];
+    const int wm0 = wm * (TM * MS), wn0 = wn * (TN * MS);
+    const int fr = lane & (MS - 1), fh = lane / MS;
+    int a_row_off[TM], a_sw[TM], b_row_off[TN], b_sw[TN];    // *_sw: byte offset of this lane's first k-chunk, swizzled
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        const int row = wm0 + t * 32 + fr;
+        const int row = wm0 + t * MS + fr;
         a_row_off[t] = row * 128;
-        a_sw[t] = (row >> 1) & 7;
+        a_sw[t] = (((row >> 1) & 7) ^ fh) << 4;
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-        const int row = wn0 + t * 32 + fr;
+        const int row = wn0 + t * MS + fr;
         b_row_off[t] = A_BYTES + row * 128;
-        b_sw[t] = (row >> 1) & 7;
+        b_sw[t] = (((row >> 1) & 7) ^ fh) << 4;
     }
 
-    f32x16 acc[TM][TN];
+    AccT acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < MS * MS / 64; ++r) acc[i][j][r] = 0.f;
 
     // ---- main loop: STAGES-deep LDS ring, LDS-DMA prefetch distance STAGES-1, one barrier per step ----
     // Iteration s: (1) wait until this thread's loads of stage s have landed, leaving the younger
@@ -450,23 +456,26 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_igemm_kernel(Conv
         const char* base = lds + cur * BUF_BYTES;
         // all fragment reads of the K-step are issued up front: the MFMAs start as soon as their
         // operands land (counted lgkmcnt) instead of exposing one LDS latency per 16-deep k slice
-        u32x4 af[4][TM], bf[4][TN];
+        u32x4 af[KK][TM], bf[KK][TN];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                af[kk][t] = *(const u32x4*)(base + a_row_off[t] + (((2 * kk + fh) ^ a_sw[t]) << 4));
+                af[kk][t] = *(const u32x4*)(base + a_row_off[t] + ((kk << KSH) ^ a_sw[t]));
 #pragma unroll
             for (int t = 0; t < TN; ++t)
-                bf[kk][t] = *(const u32x4*)(base + b_row_off[t] + (((2 * kk + fh) ^ b_sw[t]) << 4));
+                bf[kk][t] = *(const u32x4*)(base + b_row_off[t] + ((kk << KSH) ^ b_sw[t]));
         }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (BF16) {
+                    if constexpr (MS == 16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
+                    } else if constexpr (BF16) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
                     } else {
@@ -484,11 +493,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_igemm_kernel(Conv
         STAMP(4);                      // fragment reads + MFMA issue
 #endif
     }
-    #ifdef YOLO_CONV_STAMPS
-    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
+    if constexpr (EPASS == 0) {
+        STAMP(5);
+        conv_epilogue_wave<BF16, TM, TN, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, wave, lane, fr, fh);
+        STAMP(6);
+    } else {
+#ifdef YOLO_CONV_STAMPS
+    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
 #else
-    conv_epilogue<BF16, BM, BN, TM, TN, NT>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
+    conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
 #endif
+    }
 #ifdef YOLO_CONV_STAMPS
     {
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();
@@ -530,6 +545,7 @@ extern "C" int yolo_debug_read_stamps(unsigned long long* host, int n) {
 template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB, int MS, int EPASS = 1, int MINW = 1>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_kernel(ConvK p, int prows) {
     static_assert(MS == 32 || (MS == 16 && BF16), "MFMA shape");
+    static_assert(BM % (WARPS_M * MS) == 0 && BN % (WARPS_N * MS) == 0, "wave tiles must be whole MFMA tiles");
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int NT = 64 * NW;
@@ -1084,13 +1100,16 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     }
 }
 
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES>
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int MS = 32, int EPASS = 1, int MINW = 1>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
+    if constexpr (MS == 16 && !BF16) return launch_cfg<BF16, BM, BN, WARPS_M, WARPS_N, STAGES, 32, EPASS, MINW>(k, stream);
+    else {
     constexpr int loop_bytes = STAGES * (BM + BN) * 128;
-    constexpr int epi_bytes = BM * (BN + 4) * 4;
+    constexpr int epi_bytes = EPASS == 0 ? WARPS_M * WARPS_N * 32 * (BN / WARPS_N + 4) * 4 : BM / (EPASS ? EPASS : 1) * (BN + 4) * 4;
     constexpr int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto fn = conv_igemm_kernel<BF16, BM, BN, WARPS_M, WARPS_N, STAGES>;
+    if (EPASS == 0) YOLO_REQUIRE(!k.upsample && !k.reorg && !k.out_f32, YOLO_ERR_UNSUPPORTED, "conv: wave epilogue on a scatter / f32-head layer");
+    auto fn = conv_igemm_kernel<BF16, BM, BN, WARPS_M, WARPS_N, STAGES, MS, EPASS, MINW>;
     static bool attr_done[16] = {false};
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
@@ -1101,10 +1120,14 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    note_kernel("yolo::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, STAGES);
+    if (MS == 32 && EPASS == 1 && MINW == 1)
+        note_kernel("yolo::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, STAGES);
+    else
+        note_kernel("yolo::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, STAGES, MS, EPASS, MINW);
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
+    }
 }
 
 // Tile configurations.  YOLO_CONV_CFG=<id> (environment) forces one for experiments and tests.
@@ -1137,7 +1160,15 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         if (halo_ok && k.W <= 52) cfg = cfg == 65 ? 60 : 61;
         else cfg = -1;
     }
-    if (cfg >= 20 && !halo_ok) cfg = -1;
+    if (const char* im = getenv("YOLO_IGEMM_CFG")) {            // experiments: "<ksize>x<Wo>=<cfg>,..." for the layers of the im2col kernel
+        if (!halo_ok && cfg < 0 && k.Cout > 64)
+            for (const char* q = im; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+                int ks = 0, w = 0, c = 0;
+                if (sscanf(q, "%dx%d=%d", &ks, &w, &c) == 3 && ks == k.ksize && w == k.Wo) { cfg = c; break; }
+            }
+    }
+    if (cfg >= 80 && cfg < 90 && (halo_ok || k.Cout <= 64)) cfg = -1;
+    if (cfg >= 20 && cfg < 80 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
     if (cfg < 0) {
@@ -1157,13 +1188,16 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         // 16-wave 256x128 workgroup at 52x52, 7 % at 104x104)
         else if (halo_ok && (int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 80 * 1024) cfg = BF16 ? 69 : 28;
         else if (halo_ok && patch_bufs * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 26;
-        else cfg = 5;
+        else cfg = (BF16 && !k.upsample && !k.reorg && !k.out_f32) ? 81 : 5;   // 81: 5 on 16x16x32 MFMAs with the wave-private epilogue
     }
+    const bool plain = !k.upsample && !k.reorg && !k.out_f32;
     switch (cfg) {
         case 0: return launch_cfg<BF16, 128, 128, 2, 2, 2>(k, stream);     // 2 blocks/CU
         case 1: return launch_cfg<BF16, 256, 128, 4, 2, 3>(k, stream);     // 8 waves, 3-stage ring, 1 block/CU
         case 2: return launch_cfg<BF16, 128, 128, 2, 2, 3>(k, stream);     // 4 waves, 3-stage ring, 1 block/CU
-        case 3: return launch_cfg<BF16, 128, 256, 2, 4, 3>(k, stream);
+        case 3:                                                            // BN = 256: packed weights / bias are padded to 128 rows only
+            if (k.Cout % 256 == 0) return launch_cfg<BF16, 128, 256, 2, 4, 3>(k, stream);
+            return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
         case 4: return launch_cfg<BF16, 256, 128, 4, 2, 2>(k, stream);
         case 20: return launch_halo<BF16, 256, 128, 4, 2>(k, stream);
         case 21: return launch_halo<BF16, 128, 128, 2, 2>(k, stream);
@@ -1185,6 +1219,12 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 63: return launch_halo<BF16, 128, 128, 4, 2, true, 32, 0, 1>(k, stream);
         case 64: return launch_halo<BF16, 128, 128, 2, 2, true, 32, 0, 2>(k, stream);   // 4 waves of 64 x 64, up to four workgroups per CU
         case 68: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2>(k, stream);
+        case 70: case 71:                                                   // bf16 only (48 / 80 rows per wave need 16-row MFMA tiles)
+            if constexpr (BF16) {
+                if (cfg == 70) return launch_halo<true, 192, 128, 4, 2, true, 16, 0, 4>(k, stream);   // 48 x 64 per wave: 904 instead of 676 tiles at 26x26 / batch 64
+                return launch_halo<true, 320, 128, 4, 2, true, 16, 0, 2>(k, stream);                  // 80 x 64 per wave (one workgroup per CU)
+            }
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 69: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 0, 1>(k, stream);   // 28 on 16x16x32 with the wave-private epilogue
         case 40: case 41: case 42:                                          // 256 / 192 / 128 x 256 ping-pong tile, bf16 only
             if constexpr (BF16) {
@@ -1193,6 +1233,15 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
             return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 34: return launch_halo<BF16, 128, 128, 4, 2, false, 16>(k, stream);   // 24 / 28 out of 16x16x32 MFMAs
         case 38: return launch_halo<BF16, 128, 128, 4, 2, true, 16>(k, stream);
+        // im2col kernel with 64 x 64 waves / wave-private epilogue (plain and residual layers only)
+        case 80: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 32, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 5 + wave epilogue
+        case 81: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 82: if (plain) return launch_cfg<BF16, 256, 128, 4, 2, 2, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 96 KB: 1 workgroup / CU
+        case 83: if (plain) return launch_cfg<BF16, 256, 128, 4, 2, 3, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 3-stage ring, 144 KB
+        case 84: if (plain) return launch_cfg<BF16, 128, 128, 2, 2, 2, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 4 waves of 64 x 64, 2 workgroups / CU
+        case 85: if (plain) return launch_cfg<BF16, 128, 128, 2, 2, 3, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 3-stage ring, 96 KB
+        case 86: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 3, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 8 waves, 3-stage ring
+        case 87: if (plain && k.Cout % 256 == 0) return launch_cfg<BF16, 256, 256, 4, 4, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 16 waves of 64 x 64, 128 KB
         case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
