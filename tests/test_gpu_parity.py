@@ -547,7 +547,7 @@ def test_load_state_equals_load_weight_stream(net_f32, weight_stream, tmp_path):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("cfg", ["40", "41", "34", "38", "26", "5", "50", "51", "52", "60", "61", "64", "67", "80", "81", "82", "83", "84", "85", "86", "70", "71"])
+@pytest.mark.parametrize("cfg", ["40", "41", "34", "38", "26", "5", "50", "51", "52", "60", "61", "64", "67", "80", "81", "82", "83", "84", "85", "86", "70", "71", "75", "88"])
 def test_alternative_conv_tilings_vs_oracle(net_bf16, oracle, oracle_params, cfg):
     """the selectable tile configurations (YOLO_CONV_CFG: 40 / 41 = 256- / 192-row ping-pong tiles on 16x16x32 MFMAs,
     34 / 38 = the shipped tiling on 16x16x32 MFMAs, 26 = 16-wave tile, 5 = im2col) meet the bf16 tolerance of
@@ -627,3 +627,24 @@ def test_detect_batch64_416_properties(net_bf16, oracle):
         # and the whole image equals the oracle's per-class NMS run on the SAME decoded boxes / scores
         _, _, rl, ri = oracle.gpu_nms(boxes[b].cpu().numpy(), scores[b].cpu().numpy(), 80, 50, 0.5, 0.5, return_indices=True)
         assert np.array_equal(ki, ri) and np.array_equal(kl, rl)
+
+
+def test_register_epilogue_equals_lds_epilogue(net_bf16):
+    """bf16: the register epilogue (swapped 16x16x32 MFMA operands, v_permlane16_swap, no LDS: YOLO_CONV_CFG 75 for the
+    3x3 stride-1 layers, 88 for the im2col kernel) computes every output element with the same products, accumulation order
+    and roundings as the LDS-staged epilogues: the feature maps are bit-identical (also on M / N tile tails: 96 x 160, batch 3)."""
+    import os
+    import torch
+    rng = np.random.default_rng(71)
+    for B, H, W in ((3, 96, 160), (2, 416, 416)):
+        x = rng.random((B, H, W, 3), dtype=np.float32)
+        outs = {}
+        try:
+            for cfg in ("61", "75", "81", "88"):
+                os.environ["YOLO_CONV_CFG"] = cfg
+                outs[cfg] = [f.clone() for f in net_bf16.forward(x)]
+        finally:
+            del os.environ["YOLO_CONV_CFG"]
+        for a, b in (("61", "75"), ("81", "88")):
+            for fa, fb in zip(outs[a], outs[b]):
+                assert torch.equal(fa, fb), (a, b, float((fa - fb).abs().max()))

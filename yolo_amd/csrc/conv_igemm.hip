@@ -197,13 +197,93 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
     }   // pass
 }
 
+// ---- register epilogue (bf16, 16x16x32 MFMAs with the operands swapped: D[channel][pixel]) --------------------------------
+// A lane then holds, per 16x16 tile, 4 CONSECUTIVE channels (4 * (lane >> 4) + r) of ONE pixel (lane & 15): bias, activation
+// and the residual add happen in registers, v_permlane16_swap pairs two channel tiles so that every lane owns 8 consecutive
+// channels (16 bytes) of one pixel, and a store instruction writes 64 contiguous bytes per pixel.  No LDS, no barrier:
+// waves finish independently.  Same arithmetic per element as conv_epilogue: (acc + bias) -> activation -> + residual -> bf16.
+template <int TM, int TN, int ACT>
+__device__ __forceinline__ void conv_epilogue_regs_act(const ConvK& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane) {
+    static_assert(TN % 2 == 0, "channel tiles are stored in pairs");
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(p.bias + n0 + wn0 + 16 * j + 4 * fq);
+    // this lane's 16-byte piece of tile pair q: channel tile 2q + (fq & 1), channels 8 * (fq >> 1) .. + 7 of it
+    const int cpiece = wn0 + 16 * (fq & 1) + 8 * (fq >> 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + 16 * i + fr;
+        const bool mok = m < p.M;
+        const long long mrow = mok ? m : 0;
+        u32x4 rres[TN / 2];
+        if (p.res) {
+#pragma unroll
+            for (int q = 0; q < TN / 2; ++q) {
+                const int n = n0 + cpiece + 32 * q;
+                const bool ok = mok && n < p.Cout;
+                rres[q] = *(const u32x4*)(p.res + ((ok ? mrow : 0) * p.res_ld + p.res_coff + (ok ? n : 0)) * 2);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TN / 2; ++q) {
+            float va[4], vb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = acc[i][2 * q][r] + bv[2 * q][r];
+                float b = acc[i][2 * q + 1][r] + bv[2 * q + 1][r];
+                if constexpr (ACT == 1) { a = leaky_v3(a); b = leaky_v3(b); }
+                else if constexpr (ACT == 2) { a = __builtin_fmaxf(0.1f * a, a); b = __builtin_fmaxf(0.1f * b, b); }
+                va[r] = a; vb[r] = b;
+            }
+            if (p.res) {
+                // the loaded piece is in STORE order; the same swap (an involution) brings it back to accumulator order
+                const auto s0 = __builtin_amdgcn_permlane16_swap(rres[q][0], rres[q][2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(rres[q][1], rres[q][3], false, false);
+                const unsigned ra[2] = {s0[0], s1[0]}, rb[2] = {s0[1], s1[1]};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    va[2 * h] += __uint_as_float(ra[h] << 16);
+                    va[2 * h + 1] += __uint_as_float(ra[h] & 0xffff0000u);
+                    vb[2 * h] += __uint_as_float(rb[h] << 16);
+                    vb[2 * h + 1] += __uint_as_float(rb[h] & 0xffff0000u);
+                }
+            }
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            unsigned pa[2], pb[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x2 ta = {(__bf16)va[2 * h], (__bf16)va[2 * h + 1]}, tb = {(__bf16)vb[2 * h], (__bf16)vb[2 * h + 1]};
+                pa[h] = __builtin_bit_cast(unsigned, ta);
+                pb[h] = __builtin_bit_cast(unsigned, tb);
+            }
+            const auto o0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+            const auto o1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+            const int n = n0 + cpiece + 32 * q;
+            if (mok && n < p.Cout)
+                *(u32x4*)(p.out + (mrow * p.out_ld + p.out_coff + n) * 2) = u32x4{o0[0], o1[0], o0[1], o1[1]};
+        }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_regs(const ConvK& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane) {
+    if (p.leaky == 1) conv_epilogue_regs_act<TM, TN, 1>(p, acc, m0, n0, wm0, wn0, lane);
+    else if (p.leaky == 2) conv_epilogue_regs_act<TM, TN, 2>(p, acc, m0, n0, wm0, wn0, lane);
+    else conv_epilogue_regs_act<TM, TN, 0>(p, acc, m0, n0, wm0, wn0, lane);
+}
+
 // ---- wave-private epilogue (plain or residual stores only): every wave transposes its own accumulator tile through a
 // private LDS region, 32 pixel rows at a time, and stores it itself - one workgroup barrier (the staging buffers are
 // free) instead of two per pass, accumulator registers die half a tile at a time, and a wave's stores overlap the
 // other waves' transposes.  Same arithmetic as conv_epilogue: (acc + bias) -> activation -> + residual -> bf16.
 template <bool BF16, int TM, int TN, int MS, typename AccT>
 __device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[TM][TN], char* lds, int m0, int n0,
-                                                   int wm0, int wn0, int wave, int lane, int fr, int fh) {
+                                                   int wm0, int wn0, int wave, int lane, int fr, int fh
+#ifdef YOLO_CONV_STAMPS
+                                                   , unsigned long long (&st_)[8], unsigned long long& tl_
+#endif
+                                                   ) {
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int WN = TN * MS;                 // channels of the wave tile
     constexpr int LDW = WN + 4;
@@ -218,6 +298,7 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[T
 #pragma unroll
     for (int j = 0; j < TN; ++j) bv[j] = p.bias[n0 + wn0 + j * MS + fr];
     __syncthreads();                            // every wave is done reading the staging buffers
+    STAMP(5);
     const int leaky = p.leaky;
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
@@ -250,6 +331,10 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[T
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        STAMP(6);
+#ifdef YOLO_CONV_STAMPS
+        if (p.res) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(1); }     // diagnostic: residual latency still exposed here
+#endif
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = lane + it * 64;
@@ -284,6 +369,7 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[T
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging rows have been read before the next sub-pass rewrites them
         __builtin_amdgcn_wave_barrier();
+        STAMP(7);
     }
 }
 
@@ -472,7 +558,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (MS == 16) {
+                    if constexpr (MS == 16 && EPASS == 3) {       // D[channel][pixel] for the register epilogue
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, bf[kk][j]), __builtin_bit_cast(bf16x8, af[kk][i]), acc[i][j], 0, 0, 0);
+                    } else if constexpr (MS == 16) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
                     } else if constexpr (BF16) {
@@ -493,10 +582,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
         STAMP(4);                      // fragment reads + MFMA issue
 #endif
     }
-    if constexpr (EPASS == 0) {
+    if constexpr (EPASS == 3) {
+        static_assert(EPASS != 3 || (MS == 16 && BF16), "register epilogue: bf16 on 16x16x32 MFMAs");
+        if constexpr (MS == 16) conv_epilogue_regs<TM, TN>(p, acc, m0, n0, wm0, wn0, lane);
         STAMP(5);
+    } else if constexpr (EPASS == 0) {
+#ifdef YOLO_CONV_STAMPS
+        conv_epilogue_wave<BF16, TM, TN, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, wave, lane, fr, fh, st_, tl_);
+#else
         conv_epilogue_wave<BF16, TM, TN, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, wave, lane, fr, fh);
-        STAMP(6);
+#endif
     } else {
 #ifdef YOLO_CONV_STAMPS
     conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
@@ -711,7 +806,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if constexpr (MS == 16) {
+                        if constexpr (MS == 16 && EPASS == 3) {       // D[channel][pixel] for the register epilogue
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, bf[kk][j]), __builtin_bit_cast(bf16x8, af[kk][i]), acc[i][j], 0, 0, 0);
+                        } else if constexpr (MS == 16) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, af[kk][i]), __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
                         } else if constexpr (BF16) {
@@ -733,10 +831,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
 #endif
         }
     }
-    if constexpr (EPASS == 0) {
+    if constexpr (EPASS == 3) {
+        static_assert(EPASS != 3 || (MS == 16 && BF16), "register epilogue: bf16 on 16x16x32 MFMAs");
+        if constexpr (MS == 16) conv_epilogue_regs<TM, TN>(p, acc, m0, n0, wm0, wn0, lane);
         STAMP(5);
+    } else if constexpr (EPASS == 0) {
+#ifdef YOLO_CONV_STAMPS
+        conv_epilogue_wave<BF16, TM, TN, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, wave, lane, fr, fh, st_, tl_);
+#else
         conv_epilogue_wave<BF16, TM, TN, MS, AccT>(p, acc, lds, m0, n0, wm0, wn0, wave, lane, fr, fh);
-        STAMP(6);
+#endif
     } else {
 #ifdef YOLO_CONV_STAMPS
     conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh, st_, tl_);
@@ -1073,12 +1177,12 @@ static int launch_p8(const ConvK& k, hipStream_t stream) {
 
 template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32, int EPASS = 1, int MINW = 1>
 static int launch_halo(const ConvK& k, hipStream_t stream) {
-    if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32, EPASS, MINW>(k, stream);
+    if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32, EPASS == 3 ? 0 : EPASS, MINW>(k, stream);
     else {
     const int prows = (int)align_up((size_t)(BM + 2 * k.W + 2), 8);
     const int nchunks = k.Cin * (BF16 ? 2 : 4) / 128;
     const int loop_bytes = ((nchunks > 1 && !SPB) ? 2 : 1) * prows * 128 + 2 * BN * 128 + 128;
-    constexpr int epi_bytes = EPASS == 0 ? WARPS_M * WARPS_N * 32 * (BN / WARPS_N + 4) * 4 : BM / (EPASS ? EPASS : 1) * (BN + 4) * 4;
+    constexpr int epi_bytes = EPASS == 3 ? 0 : EPASS == 0 ? WARPS_M * WARPS_N * 32 * (BN / WARPS_N + 4) * 4 : BM / (EPASS ? EPASS : 1) * (BN + 4) * 4;
     const int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
     YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 halo: W=%d needs %d bytes of LDS", k.W, lds_bytes);
     YOLO_REQUIRE((long long)k.M * k.in_ld * (BF16 ? 2 : 4) < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 halo: input larger than 4 GiB");
@@ -1102,13 +1206,13 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
 
 template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int MS = 32, int EPASS = 1, int MINW = 1>
 static int launch_cfg(const ConvK& k, hipStream_t stream) {
-    if constexpr (MS == 16 && !BF16) return launch_cfg<BF16, BM, BN, WARPS_M, WARPS_N, STAGES, 32, EPASS, MINW>(k, stream);
+    if constexpr (MS == 16 && !BF16) return launch_cfg<BF16, BM, BN, WARPS_M, WARPS_N, STAGES, 32, EPASS == 3 ? 0 : EPASS, MINW>(k, stream);
     else {
     constexpr int loop_bytes = STAGES * (BM + BN) * 128;
-    constexpr int epi_bytes = EPASS == 0 ? WARPS_M * WARPS_N * 32 * (BN / WARPS_N + 4) * 4 : BM / (EPASS ? EPASS : 1) * (BN + 4) * 4;
+    constexpr int epi_bytes = EPASS == 3 ? 0 : EPASS == 0 ? WARPS_M * WARPS_N * 32 * (BN / WARPS_N + 4) * 4 : BM / (EPASS ? EPASS : 1) * (BN + 4) * 4;
     constexpr int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    if (EPASS == 0) YOLO_REQUIRE(!k.upsample && !k.reorg && !k.out_f32, YOLO_ERR_UNSUPPORTED, "conv: wave epilogue on a scatter / f32-head layer");
+    if (EPASS == 0 || EPASS == 3) YOLO_REQUIRE(!k.upsample && !k.reorg && !k.out_f32, YOLO_ERR_UNSUPPORTED, "conv: wave epilogue on a scatter / f32-head layer");
     auto fn = conv_igemm_kernel<BF16, BM, BN, WARPS_M, WARPS_N, STAGES, MS, EPASS, MINW>;
     static bool attr_done[16] = {false};
     int dev = 0;
@@ -1155,6 +1259,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         if (halo_ok && k.W <= 32) cfg = cfg == 53 ? 50 : cfg == 54 ? 51 : cfg == 55 ? 60 : 61;
         else cfg = -1;
     }
+    if (cfg == 75) cfg = !halo_ok ? -1 : k.W <= 16 ? 73 : k.W <= 52 ? 72 : 74;   // the shipped tile choice with the register epilogue
     if (cfg == 67) cfg = !halo_ok ? -1 : k.W <= 32 ? 62 : 63;    // the shipped tiling with the wave-private epilogue
     if (cfg >= 65 && cfg <= 66) {                               // ... and up to 52 x 52
         if (halo_ok && k.W <= 52) cfg = cfg == 65 ? 60 : 61;
@@ -1188,7 +1293,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         // 16-wave 256x128 workgroup at 52x52, 7 % at 104x104)
         else if (halo_ok && (int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 80 * 1024) cfg = BF16 ? 69 : 28;
         else if (halo_ok && patch_bufs * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 26;
-        else cfg = (BF16 && !k.upsample && !k.reorg && !k.out_f32) ? 81 : 5;   // 81: 5 on 16x16x32 MFMAs with the wave-private epilogue
+        else cfg = (BF16 && !k.upsample && !k.reorg && !k.out_f32) ? 88 : 5;   // 88: 5 on 16x16x32 MFMAs with the register epilogue (+8 % on the 1x1 layers)
     }
     const bool plain = !k.upsample && !k.reorg && !k.out_f32;
     switch (cfg) {
@@ -1219,6 +1324,9 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 63: return launch_halo<BF16, 128, 128, 4, 2, true, 32, 0, 1>(k, stream);
         case 64: return launch_halo<BF16, 128, 128, 2, 2, true, 32, 0, 2>(k, stream);   // 4 waves of 64 x 64, up to four workgroups per CU
         case 68: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2>(k, stream);
+        case 72: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 3, 4>(k, stream);   // 61 / 68 / 69 with the register epilogue
+        case 73: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 3, 2>(k, stream);
+        case 74: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 3, 1>(k, stream);
         case 70: case 71:                                                   // bf16 only (48 / 80 rows per wave need 16-row MFMA tiles)
             if constexpr (BF16) {
                 if (cfg == 70) return launch_halo<true, 192, 128, 4, 2, true, 16, 0, 4>(k, stream);   // 48 x 64 per wave: 904 instead of 676 tiles at 26x26 / batch 64
@@ -1242,6 +1350,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 85: if (plain) return launch_cfg<BF16, 128, 128, 2, 2, 3, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 3-stage ring, 96 KB
         case 86: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 3, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 8 waves, 3-stage ring
         case 87: if (plain && k.Cout % 256 == 0) return launch_cfg<BF16, 256, 256, 4, 4, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 16 waves of 64 x 64, 128 KB
+        case 88: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 3, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 81 with the register epilogue
         case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
