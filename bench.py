@@ -7,8 +7,16 @@ A step = one pass of the hot path over one batch of 64 synthetic 416x416 images 
 already resident in HBM: yolov3.forward (bf16 MFMA conv stack) -> predict -> conf*prob -> per-class NMS
 (gpu_nms defaults 50 / 0.5 / 0.5; the three post-processing steps run fused, yolo_detect_post).  Images are independent, so ranks share nothing
 (weak scaling, no collective in the timed region).  Rank 0 prints ONE JSON line.
+
+Beside the headline value the line carries (all measured in this run):
+  roofline          dominant conv kernel against the dense bf16 MFMA peak (HIP events on the launch stream)
+  fp32              the same step in the reference's own precision (parity path), short pass
+  sharded_512       BASELINE config 3: a 512-image batch cut with shard_bounds over the ranks, local steps of 64
+  post_processing   yolo_detect_post alone against HBM;  decode: API-level yolo_decode (predict + scores) against HBM
+  cpu_baseline      the oracle (CPU restatement of the reference) on the host cores, bounded sample
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,25 +30,41 @@ sys.path.insert(0, ROOT)
 
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 F32_PEAK_TFLOPS = 157.3
-# HBM-side bytes per launch of a kernel instantiation, from the committed PMC passes (profiles/, see DESIGN.md
-# section 5): 2 x FETCH_SIZE + WRITE_SIZE averaged over the launches of one bench step (FETCH_SIZE doubled as
-# MI355X_MICROARCH.md "HBM" prescribes for gfx950).  Keyed by (kernel, batch, size); None when not measured.
-TRAFFIC_BYTES_PER_LAUNCH = {
-    # profiles/r1_bench_pmc_traffic_v5_lanes1.txt (one launch per layer over the full batch, as the roofline is measured):
-    # halo kernel, two patch buffers: fetch 138.70 MB (2 x FETCH_SIZE) + write 35.69 MB
-    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, false, 32>", 64, 416): 174.39e6,
-    ("yolo::conv3x3_halo_kernel<true, 128, 128, 4, 2, true, 32>", 64, 416): 245.34e6,
-    ("yolo::conv_igemm_kernel<true, 128, 128, 4, 2, 2>", 64, 416): 119.59e6,
-}
+HBM_PEAK_GBS = 8000.0
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "traffic_table.json")
+
+
+def kernel_sources_sha():
+    """Hash of the kernel sources: the PMC traffic table is only valid for the sources it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "yolo_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_for(kernel, B, S):
+    """HBM-side bytes per launch of `kernel` from the PMC passes scripts/gpu_profile.sh wrote (2 x FETCH_SIZE + WRITE_SIZE,
+    MI355X_MICROARCH.md "HBM"); None (with the reason) when the table is missing or was measured on other sources."""
+    if not os.path.exists(TRAFFIC_TABLE):
+        return None, "no profiles/traffic_table.json"
+    t = json.load(open(TRAFFIC_TABLE))
+    if t.get("sources_sha") != kernel_sources_sha():
+        return None, "traffic table measured on other kernel sources (%s): re-run scripts/gpu_profile.sh" % t.get("sources_sha")
+    if (t.get("batch"), t.get("size")) != (B, S):
+        return None, "traffic table measured at batch %s / %s" % (t.get("batch"), t.get("size"))
+    for name, v in t.get("kernels", {}).items():
+        if kernel in name:
+            return v["total_bytes"], "profiles/traffic_table.json (%s)" % t.get("command", "")
+    return None, "kernel not in the traffic table"
 
 
 def conv_flops_per_image(info, H, W):
     """2*MAC per conv: output resolution follows the strides along the plan."""
-    # resolution of every conv's OUTPUT: replay the architecture (stride-2 convs halve; the two
-    # upsample branches return to the route resolution; heads keep theirs).
     flops = []
     h, w = H, W
-    res_at = {}
     for i, (cin, cout, k, s) in enumerate(info):
         if i == 59:            # inter1 conv consumes conv 56's output (13x13)
             h, w = H // 32, W // 32
@@ -56,22 +80,82 @@ def conv_flops_per_image(info, H, W):
 
 
 def cpu_baseline(n_images, threads):
-    """The oracle (CPU restatement of the reference: TF is not installable offline) on host cores."""
+    """The oracle (CPU restatement of the reference: TF is not installable offline) on host cores: batch 1 with the
+    stages timed apart (conv stack / decode / per-class NMS), then a batch-8 figure."""
     from oracle import yolo_oracle as O
     torch.set_num_threads(threads)
     specs = O.yolov3_conv_specs(80)
     params = O.split_darknet_stream(specs, O.synth_darknet_stream(specs, seed=1234))
     rng = np.random.default_rng(0)
-    img = rng.random((1, 416, 416, 3), dtype=np.float32)
-    O.detect(params, O.YOLO_ANCHORS, img, max_boxes=50, score_thresh=0.5, iou_thresh=0.5)     # warm
-    t0 = time.perf_counter()
-    for i in range(n_images):
-        img = rng.random((1, 416, 416, 3), dtype=np.float32)
-        O.detect(params, O.YOLO_ANCHORS, img, max_boxes=50, score_thresh=0.5, iou_thresh=0.5)
-    dt = time.perf_counter() - t0
-    return {"value": n_images / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d images, batch 1, 416x416, oracle forward+predict+gpu_nms(50,0.5,0.5), torch-CPU fp32 convs "
-                      "(CPU restatement of the reference; TensorFlow not installable offline)" % n_images}
+
+    def one(img, acc):
+        t0 = time.perf_counter()
+        fms = O.forward(params, img)
+        t1 = time.perf_counter()
+        b, c, p = O.predict(fms, O.YOLO_ANCHORS, img.shape[1:3])
+        s = (c * p).astype(np.float32)
+        t2 = time.perf_counter()
+        for i in range(img.shape[0]):
+            O.gpu_nms(b[i], s[i], 80, 50, 0.5, 0.5)
+        t3 = time.perf_counter()
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2
+
+    one(rng.random((1, 416, 416, 3), dtype=np.float32), [0.0, 0.0, 0.0])      # warm
+    st1 = [0.0, 0.0, 0.0]
+    for _ in range(n_images):
+        one(rng.random((1, 416, 416, 3), dtype=np.float32), st1)
+    dt1 = sum(st1)
+    st8 = [0.0, 0.0, 0.0]
+    n8 = max(1, n_images // 16)
+    for _ in range(n8):
+        one(rng.random((8, 416, 416, 3), dtype=np.float32), st8)
+    dt8 = sum(st8)
+    return {"value": round(n_images / dt1, 3), "unit": "images/sec", "cores": threads, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": "%d images at batch 1 + %d at batch 8, 416x416, oracle forward + predict + conf*prob + gpu_nms(50,0.5,0.5), "
+                      "torch-CPU fp32 convs on %d threads (CPU restatement of the reference; TensorFlow not installable offline)"
+                      % (n_images, 8 * n8, threads),
+            "batch1_ms_per_image": {"conv": round(st1[0] / n_images * 1e3, 2), "decode": round(st1[1] / n_images * 1e3, 2),
+                                    "nms": round(st1[2] / n_images * 1e3, 2)},
+            "batch8": {"images_per_sec": round(8 * n8 / dt8, 3),
+                       "ms_per_image": {"conv": round(st8[0] / (8 * n8) * 1e3, 2), "decode": round(st8[1] / (8 * n8) * 1e3, 2),
+                                        "nms": round(st8[2] / (8 * n8) * 1e3, 2)}}}
+
+
+def dominant_kernel(net, images, dtype, B, S, lanes, reps=5):
+    """Per-layer HIP events recorded by the library on the launch stream (yolo_net_forward_timed), layers grouped by the
+    kernel INSTANTIATION the library launched for them; the group with the most time is the dominant kernel."""
+    acc = None
+    for _ in range(reps):
+        _, ms, info = net.forward_timed(images)
+        acc = ms.astype(np.float64) if acc is None else acc + ms
+    layer_ms = acc / reps
+    kernels = net.layer_kernels
+    flops = conv_flops_per_image(info, S, S)
+    groups = {}
+    for i, name in enumerate(kernels):
+        g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        g["launches"] += 1
+        g["ms"] += float(layer_ms[i])
+        g["flops"] += flops[i] * B
+    dom_name = max(groups, key=lambda n: groups[n]["ms"])
+    dom = groups[dom_name]
+    peak = BF16_PEAK_TFLOPS if dtype == "bf16" else F32_PEAK_TFLOPS
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    traffic, traffic_src = traffic_for(dom_name, B, S) if dtype == "bf16" else (None, "not measured for fp32")
+    roofline = {"bound": "mfma", "kernel": dom_name,
+                "measured": "HIP events around every layer of one launch per layer over the full batch (yolo_net_forward_timed); "
+                            "the timed steps run the same kernels as %d concurrent lane(s) of ~%d images" % (lanes, B // lanes),
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": dom["launches"],
+                "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
+                "flops_per_launch_avg": dom["flops"] / dom["launches"],
+                "share_of_conv_stack_ms": round(dom["ms"] / float(layer_ms.sum()), 3),
+                "conv_stack_ms": round(float(layer_ms.sum()), 4),
+                "conv_stack_tflops": round(sum(flops) * B / (float(layer_ms.sum()) * 1e-3) / 1e12, 2),
+                "kernels": [{"kernel": n, "launches": g["launches"], "ms": round(g["ms"], 4),
+                             "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 1)}
+                            for n, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]}
+    return roofline, layer_ms, info, flops, kernels
 
 
 def main():
@@ -82,8 +166,12 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--global-batch", type=int, default=512,
+                    help="BASELINE config 3 (extra record `sharded_512`): images of ONE batch cut over the ranks with shard_bounds, "
+                         "each rank runs its shard in local steps of --batch; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=32, help="images of the CPU baseline sample (about 10 s of host work)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / sharded / decode side records (profiling runs)")
+    ap.add_argument("--cpu-images", type=int, default=16, help="batch-1 images of the CPU baseline sample (+ the same number at batch 8)")
     ap.add_argument("--layer-table", default="", help="write the per-layer timing table to this file")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run concurrently on separate streams inside the library "
                                                          "(YOLO_LANES); 0 = library default (2 from batch 12 up, 3 from batch 48 up)")
@@ -107,6 +195,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
 
     from yolo_amd.model import yolov3
+    from yolo_amd.shard import shard_bounds
     from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
     from yolo_amd.weights import synth_darknet_stream
 
@@ -116,65 +205,35 @@ def main():
     rng = np.random.default_rng(1 + rank)
     images = torch.from_numpy(rng.random((B, S, S, 3), dtype=np.float32)).cuda()
 
-    def step():
-        # forward -> predict -> conf*prob -> per-class NMS (gpu_nms defaults), the last three as one library call
-        return net.detect(images, 50, 0.5, 0.5)
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ndet = int(out[4].sum().item())
+    def timed(fn, steps, warmup):
+        """W untimed + exactly K timed calls between barrier + synchronize; MAX over ranks."""
+        out = None
+        for _ in range(warmup):
+            out = fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
 
-    # ---- roofline of the dominant kernel: per-layer HIP events recorded by the library on the launch stream
-    # (yolo_net_forward_timed), layers grouped by the kernel INSTANTIATION the library launched for them ----
-    reps = 5
-    acc = None
-    for _ in range(reps):
-        _, ms, info = net.forward_timed(images)
-        acc = ms.astype(np.float64) if acc is None else acc + ms
-    layer_ms = acc / reps
-    kernels = net.layer_kernels
-    flops = conv_flops_per_image(info, S, S)
-    groups = {}
-    for i, name in enumerate(kernels):
-        g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
-        g["launches"] += 1
-        g["ms"] += float(layer_ms[i])
-        g["flops"] += flops[i] * B
-    dom_name = max(groups, key=lambda n: groups[n]["ms"])
-    dom = groups[dom_name]
-    peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((dom_name, B, S))
+    # forward -> predict -> conf*prob -> per-class NMS (gpu_nms defaults), the last three fused, as one library call
+    dt, out = timed(lambda: net.detect(images, 50, 0.5, 0.5), args.steps, args.warmup)
+    ndet = int(out[4].sum().item())
     lanes = int(os.environ.get("YOLO_LANES", "0")) or (3 if B >= 48 else 2 if B >= 12 else 1)
-    roofline = {"bound": "mfma", "kernel": dom_name,
-                "measured": "HIP events around every layer of one launch per layer over the full batch (yolo_net_forward_timed); "
-                            "the timed steps run the same kernels as %d concurrent lane(s) of ~%d images" % (lanes, B // lanes),
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "launches_per_step": dom["launches"],
-                "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
-                "flops_per_launch_avg": dom["flops"] / dom["launches"],
-                "share_of_conv_stack_ms": round(dom["ms"] / float(layer_ms.sum()), 3),
-                "conv_stack_ms": round(float(layer_ms.sum()), 4),
-                "conv_stack_tflops": round(sum(flops) * B / (float(layer_ms.sum()) * 1e-3) / 1e12, 2),
-                "kernels": [{"kernel": n, "launches": g["launches"], "ms": round(g["ms"], 4),
-                             "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 1)}
-                            for n, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]}
+
+    roofline, layer_ms, info, flops, kernels = dominant_kernel(net, images, args.dtype, B, S, lanes)
     if args.layer_table and rank == 0:
         with open(args.layer_table, "w") as f:
             f.write("# layer cin cout k stride ms GFLOP TFLOP/s   (batch %d, %dx%d, %s)\n" % (B, S, S, args.dtype))
@@ -182,55 +241,105 @@ def main():
                 f.write("%2d %4d %4d %d %d %8.4f %9.3f %8.2f  %s\n" % (i, cin, cout, k, s, ms_i, flops[i] * B / 1e9,
                                                                        flops[i] * B / (ms_i * 1e-3) / 1e12, kernels[i]))
 
+    def event_ms(fn, reps=20, warm=3):
+        for _ in range(warm):
+            fn()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / reps
+
     # ---- post-processing alone (decode + conf*prob + score mask + per-class NMS, fused: yolo_detect_post) on the feature
-    # maps of the last forward: HBM-bound by SURVEY.md 8(d); algorithmic bytes per image = decode 7.24 MB (read 3 fms,
-    # write boxes + confs + probs) + NMS 3.58 MB (read boxes + scores) at 416 - what the separate reference calls move
+    # maps of the last forward.  HBM-bound by SURVEY.md 8(d); `frac` prices the bytes the fused call has to move (read the
+    # three feature maps, write the decoded boxes); the bytes the reference's separate predict + gpu_nms calls would move
+    # (7.24 + 3.58 MB/img) are a named extra, not a roofline fraction.
     fms = net.forward(images)
-    for _ in range(3):
-        net.postprocess(fms, 50, 0.5, 0.5)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(20):
-        net.postprocess(fms, 50, 0.5, 0.5)
-    ev1.record()
-    torch.cuda.synchronize()
-    post_ms = ev0.elapsed_time(ev1) / 20
     n_boxes = 3 * ((S // 32) ** 2 + (S // 16) ** 2 + (S // 8) ** 2)
-    post_bytes = B * (2.0 * n_boxes * 85 * 4 + n_boxes * 84 * 4)
-    fused_bytes = B * (n_boxes * 85 * 4 + n_boxes * 16)            # what the fused call must move: read fms, write boxes
-    post = {"bound": "hbm", "ms": round(post_ms, 4), "peak": 8000.0, "unit": "GB/s",
-            "achieved": round(post_bytes / (post_ms * 1e-3) / 1e9, 1), "frac": round(post_bytes / (post_ms * 1e-3) / 8e12, 4),
-            "achieved_fused_bytes": round(fused_bytes / (post_ms * 1e-3) / 1e9, 1),
-            "what": "yolo_detect_post on %d images (%d boxes x 80 classes each, thresholds 50 / 0.5 / 0.5), HIP events on the launch stream; "
-                    "`achieved` prices the algorithmic bytes of the reference's separate predict + gpu_nms calls (10.82 MB/img), "
-                    "`achieved_fused_bytes` the 3.79 MB/img the fused call really has to move" % (B, n_boxes)}
+    post_ms = event_ms(lambda: net.postprocess(fms, 50, 0.5, 0.5))
+    fused_bytes = B * (n_boxes * 85 * 4 + n_boxes * 16)
+    ref_bytes = B * (2.0 * n_boxes * 85 * 4 + n_boxes * 84 * 4)
+    post = {"bound": "hbm", "ms": round(post_ms, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": round(fused_bytes / (post_ms * 1e-3) / 1e9, 1), "frac": round(fused_bytes / (post_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "reference_bytes_rate": round(ref_bytes / (post_ms * 1e-3) / 1e9, 1),
+            "what": "yolo_detect_post on %d images (%d boxes x 80 classes each, thresholds 50 / 0.5 / 0.5), events on the launch stream; "
+                    "`achieved` = the %.2f MB/img the fused call must move (feature maps in, boxes out); `reference_bytes_rate` prices "
+                    "the 10.82 MB/img of the reference's separate predict + gpu_nms calls and is not a roofline fraction; the stage is "
+                    "latency-bound by the per-class selection, not by HBM" % (B, n_boxes, fused_bytes / B / 1e6)}
+
+    side = {}
+    if not args.no_extras:
+        # ---- API-level predict (+ scores): yolo_decode, algorithmic bytes SURVEY.md 8(d) = 7.24 + 3.41 MB/img at 416
+        dec_ms = event_ms(lambda: net.predict(fms, return_scores=True))
+        dec_bytes = B * (2.0 * n_boxes * 85 * 4 + n_boxes * 80 * 4)
+        side["decode"] = {"bound": "hbm", "ms": round(dec_ms, 4), "achieved": round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "what": "yolo_decode = predict + conf*prob on %d images: reads 3 feature maps, writes boxes, confs, probs, scores "
+                                  "(%.2f MB/img algorithmic), events on the launch stream; includes the output allocation of the mirror" %
+                                  (B, dec_bytes / B / 1e6)}
+
+        # ---- BASELINE config 3: ONE batch of --global-batch images, contiguous shards (shard_bounds), local steps of --batch
+        if args.global_batch > 0:
+            G = args.global_batch
+            lo, hi = shard_bounds(G, rank, world)
+            n_local = hi - lo
+            shard = torch.empty((n_local, S, S, 3), dtype=torch.float32, device="cuda")
+            for j in range(0, n_local, 64):            # per-image seeds: the global batch does not depend on the split
+                k = min(64, n_local - j)
+                blk = np.stack([np.random.default_rng([2, lo + j + i]).random((S, S, 3), dtype=np.float32) for i in range(k)])
+                shard[j:j + k] = torch.from_numpy(blk).cuda()
+
+            def shard_pass():
+                outs = []
+                for j in range(0, n_local, B):
+                    outs.append(net.detect(shard[j:j + B], 50, 0.5, 0.5))
+                return outs
+            reps = max(2, min(4, args.steps))
+            dts, outs = timed(shard_pass, reps, 1)
+            nd = sum(int(o[4].sum().item()) for o in outs)
+            if dist is not None:
+                t = torch.tensor([nd], dtype=torch.int64, device="cuda")
+                dist.all_reduce(t)
+                nd = int(t.item())
+            side["sharded_512"] = {"global_batch": G, "n_gpus": world, "images_per_sec": round(G * reps / dts, 2),
+                                   "ms_per_global_batch": round(dts / reps * 1e3, 3), "local_images_rank0": n_local,
+                                   "local_steps_rank0": (n_local + B - 1) // B, "scaling": "strong", "detections": nd,
+                                   "what": "BASELINE config 3: shard_bounds(%d, rank, %d), every rank runs its contiguous shard in local "
+                                           "steps of %d, no collective in the timed region; efficiency vs the 1-GPU figure of this key is "
+                                           "the driver's to compute" % (G, world, B)}
+            del shard
+
+        # ---- the reference's own precision (fp32 parity path), short pass: value + dominant kernel against the f32 matrix peak
+        if args.dtype == "bf16":
+            del fms
+            net32 = yolov3(80, DEFAULT_ANCHORS, dtype="fp32").load_weight_stream(stream)
+            dt32, _ = timed(lambda: net32.detect(images, 50, 0.5, 0.5), 4, 1)
+            r32, _, _, _, _ = dominant_kernel(net32, images, "fp32", B, S, lanes, reps=2)
+            side["fp32"] = {"images_per_sec": round(world * B * 4 / dt32, 2), "ms_per_step": round(dt32 / 4 * 1e3, 3), "steps": 4,
+                            "dominant_kernel": r32["kernel"], "achieved": r32["achieved"], "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": r32["frac"], "conv_stack_ms": r32["conv_stack_ms"], "conv_stack_tflops": r32["conv_stack_tflops"],
+                            "what": "same step with the conv stack on exact-f32 MFMAs (v_mfma_f32_32x32x2_f32): the parity path"}
+            del net32
 
     h2d = None
     if args.h2d:
         from yolo_amd.preprocess import preprocess
         host = images.cpu().pin_memory()
         host_u8 = torch.from_numpy(rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)).pin_memory()
-
-        def timed(fn):
-            for _ in range(2):
-                fn()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                fn()
-            barrier()
-            return (time.perf_counter() - t0) / args.steps
-
-        dth = timed(lambda: net.detect(host.to("cuda", non_blocking=True), 50, 0.5, 0.5))
-        dtu = timed(lambda: net.detect(preprocess(host_u8.to("cuda", non_blocking=True), (S, S)), 50, 0.5, 0.5))
+        dth = timed(lambda: net.detect(host.to("cuda", non_blocking=True), 50, 0.5, 0.5), args.steps, 2)[0] / args.steps
+        dtu = timed(lambda: net.detect(preprocess(host_u8.to("cuda", non_blocking=True), (S, S)), 50, 0.5, 0.5), args.steps, 2)[0] / args.steps
         from yolo_amd.pipeline import DetectPipeline
         pipe = DetectPipeline(net, (S, S), 50, 0.5, 0.5)
-        for _ in pipe.run([host_u8] * 3):
-            pass
+
+        def piped(n):
+            for _ in pipe.run([host_u8] * n):
+                pass
+        piped(3)
         barrier()
         t0 = time.perf_counter()
-        for _ in pipe.run([host_u8] * args.steps):
-            pass
+        piped(args.steps)
         barrier()
         dtp = (time.perf_counter() - t0) / args.steps
         h2d = {"images_per_sec": round(B / dth, 2), "ms_per_step": round(dth * 1e3, 4),
@@ -258,6 +367,7 @@ def main():
             "roofline": roofline,
         }
         res["post_processing"] = post
+        res.update(side)
         if h2d is not None:
             res["pcie_inclusive"] = h2d
         if world == 1 and not args.no_cpu_baseline:

@@ -115,7 +115,10 @@ int yolo_reorg_boxes(const float* fm, int B, int gh, int gw, int H, int W, int c
  * boxes [B,n,4], scores [B,n,C]: each of the B images is processed independently (the reference's
  * batch-flattening behaviour is obtained by calling with B=1, n=B*n).
  * Outputs per image i at rows [i*C*max_boxes, ...): class-ascending, selection order inside a class;
- * out_counts[i] = number of valid rows; out_index = index of the box inside its image (keep-index). */
+ * out_counts[i] = number of valid rows; out_index = index of the box inside its image (keep-index).
+ * Limits (beyond the reference, which has none): max_boxes <= 1024 (the selected boxes of a class live in LDS) and
+ * class_num <= 4096; yolo_detect_post / yolo_net_detect also need class_num <= 250.  The *_workspace_bytes functions return 0
+ * for arguments outside these limits, the calls YOLO_ERR_UNSUPPORTED. */
 size_t yolo_nms_workspace_bytes(int B, int n, int class_num, int max_boxes);
 int yolo_nms(const float* boxes, const float* scores, int B, int n, int class_num, int max_boxes,
              float score_thresh, float iou_thresh, int mode, float* out_boxes, float* out_scores,
@@ -154,6 +157,16 @@ size_t yolo_net_detect_workspace_bytes(const YoloNet* net, int B, int H, int W, 
 int yolo_net_detect(YoloNet* net, const float* images, int B, int H, int W, const float* anchors, int max_boxes,
                     float score_thresh, float iou_thresh, float* out_boxes, float* out_scores, int32_t* out_labels,
                     int32_t* out_index, int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- detections of a batch -> one dense row list: replaces the box rescale the reference's drivers do
+ * on the host after sess.run (yolo_v3/test_single_image.py:42-45, yolo_v3/video_test.py:67-71: x *= width_ori / new_w,
+ * y *= height_ori / new_h in float32) and fixes the wire format a sharded run gathers.  boxes [B,cap,4], scores [B,cap],
+ * labels [B,cap], counts [B]: the outputs of yolo_nms / yolo_detect_post / yolo_net_detect (cap = class_num * max_boxes).
+ * scale_xy: DEVICE float32 [B,2] = (width_ori / new_w, height_ori / new_h) per image, or NULL (boxes stay in network pixels).
+ * rows: DEVICE float32 [B*cap, 7], filled densely in image order with (image_base + image index, x0, y0, x1, y1, score,
+ * label); offsets: DEVICE int32 [B+1], rows of image i are [offsets[i], offsets[i+1]); offsets[B] = number of rows. */
+int yolo_pack_detections(const float* boxes, const float* scores, const int32_t* labels, const int32_t* counts, int B,
+                         int cap, const float* scale_xy, int image_base, float* rows, int32_t* offsets, void* stream);
 
 /* ---- image preprocessing: replaces the host-side steps before the network,
  * cv2.resize(img, new_size) [INTER_LINEAR, 8-bit fixed point] -> cv2.cvtColor(BGR2RGB) -> float32(img) / 255.

@@ -1,9 +1,13 @@
 """HBM-side bytes per launch per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; both in KiB).
 gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM) -> doubled here.
-python scripts/pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass>"""
+python scripts/pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> [table.json batch size "command"]
+With the last four arguments also writes the table bench.py reads (profiles/traffic_table.json), stamped with the hash of
+the kernel sources it was measured on."""
 import collections
 import csv
 import glob
+import json
+import os
 import sys
 
 
@@ -26,3 +30,10 @@ for k in fetch:
     rows.append((f + w, k, len(fetch[k]), f, w))
 for tot, k, n, f, w in sorted(rows, reverse=True):
     print("%-88s %7d %10.2f %10.2f %10.2f" % (k[:88], n, f, w, tot))
+if len(sys.argv) > 6:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    table = {"sources_sha": bench.kernel_sources_sha(), "batch": int(sys.argv[4]), "size": int(sys.argv[5]), "command": sys.argv[6],
+             "kernels": {k: {"calls": n, "fetch_bytes": f * 1e6, "write_bytes": w * 1e6, "total_bytes": tot * 1e6}
+                         for tot, k, n, f, w in rows if "yolo::" in k}}
+    json.dump(table, open(sys.argv[3], "w"), indent=1, sort_keys=True)

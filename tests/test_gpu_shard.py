@@ -1,0 +1,167 @@
+"""GPU tests of the rows either side of the hot path and of the bf16 detection tolerance:
+sharded batch = unsharded batch, device-side box rescale + wire rows against the reference's host arithmetic,
+bf16 detections against the fp32 oracle's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net_bf16(torch_cuda, oracle, weight_stream):
+    from yolo_amd.model import yolov3
+    return yolov3(80, oracle.YOLO_ANCHORS, dtype="bf16").load_weight_stream(weight_stream)
+
+
+def test_sharded_batch_equals_unsharded(net_bf16):
+    """BASELINE config 3 on one GPU: a 128-image batch cut with shard_bounds into G = 2 / 4 / 8 contiguous shards (as G
+    processes would), each shard through detect -> pack_detections_device(image_base = lo); the concatenated row lists
+    equal the unsharded run's rows bit for bit.  Uneven shards (G = 3, 7 of 13 images) as well."""
+    import torch
+    from yolo_amd.shard import pack_detections_device, shard_bounds
+    rng = np.random.default_rng(2)
+    for n, size, groups in ((128, 416, (2, 4, 8)), (13, 96, (3, 7))):
+        x = torch.from_numpy(rng.random((n, size, size, 3), dtype=np.float32)).cuda()
+        thr = 0.5 if size == 416 else 0.05
+        outs = []
+        for j in range(0, n, 64):                                     # local steps of 64 like bench.py's sharded pass
+            ob, osc, ol, _, oc = net_bf16.detect(x[j:j + 64], 50, thr, 0.5)
+            rows, off = pack_detections_device(ob, osc, ol, oc, None, j)
+            outs.append((rows.clone(), off.clone()))
+        ref_rows = torch.cat([r for r, _ in outs])
+        assert ref_rows.shape[0] > 50
+        assert bool((ref_rows[1:, 0] >= ref_rows[:-1, 0]).all()) and int(ref_rows[-1, 0]) < n      # image order
+        for G in groups:
+            parts = []
+            for rank in range(G):
+                lo, hi = shard_bounds(n, rank, G)
+                for j in range(lo, hi, 64):
+                    k = min(hi, j + 64)
+                    ob, osc, ol, _, oc = net_bf16.detect(x[j:k], 50, thr, 0.5)
+                    rows, off = pack_detections_device(ob, osc, ol, oc, None, j)
+                    assert int(off[-1]) == rows.shape[0]
+                    parts.append(rows.clone())
+            got = torch.cat(parts)
+            assert got.shape == ref_rows.shape and torch.equal(got, ref_rows), G
+
+
+def test_pack_detections_rescale_vs_reference_arithmetic(torch_cuda, oracle):
+    """yolo_pack_detections = the reference's host-side rescale (test_single_image.py:42-45: float32 boxes *= python float
+    ratio, in place) + row format, bit-exact against that arithmetic on the oracle's NMS output."""
+    from yolo_amd.shard import pack_detections_device
+    from yolo_amd.utils import nms_utils
+    rng = np.random.default_rng(12)
+    B, n, C = 3, 2000, 5
+    xy = rng.random((B, n, 2)) * 380
+    wh = rng.random((B, n, 2)) * 100 + 1
+    boxes = np.concatenate([xy, xy + wh], 2).astype(np.float32)
+    scores = (rng.random((B, n, C)) ** 3).astype(np.float32)
+    scores[1] = 0.0                                                   # an image without detections in the middle
+    ob, osc, ol, oi, oc = nms_utils.gpu_nms_batched(boxes, scores, C, 15, 0.5, 0.45)
+    sizes = [(768, 576), (1920, 1080), (333, 517)]                    # (width_ori, height_ori) per image
+    new_size = (416, 416)
+    scale = np.asarray([[w / float(new_size[0]), h / float(new_size[1])] for w, h in sizes], np.float32)
+    rows, off = pack_detections_device(ob, osc, ol, oc, scale, image_base=40)
+    rows, off = rows.cpu().numpy(), off.cpu().numpy()
+    assert off[0] == 0 and off[2] == off[1] and off[-1] == rows.shape[0] > 10
+    for b in range(B):
+        rb, rs, rl = oracle.gpu_nms(boxes[b], scores[b], C, 15, 0.5, 0.45)
+        boxes_ = np.array(rb, np.float32).reshape(-1, 4)
+        w, h = sizes[b]
+        boxes_[:, 0] *= (w / float(new_size[0]))                      # test_single_image.py:42-45
+        boxes_[:, 2] *= (w / float(new_size[0]))
+        boxes_[:, 1] *= (h / float(new_size[1]))
+        boxes_[:, 3] *= (h / float(new_size[1]))
+        r = rows[off[b]:off[b + 1]]
+        assert len(r) == len(rl)
+        np.testing.assert_array_equal(r[:, 0], np.float32(40 + b))
+        np.testing.assert_array_equal(r[:, 1:5], boxes_)
+        np.testing.assert_array_equal(r[:, 5], rs)
+        np.testing.assert_array_equal(r[:, 6].astype(np.int32), rl)
+    rows2, off2 = pack_detections_device(ob, osc, ol, oc)             # no scale: boxes stay in network pixels
+    assert np.array_equal(off2.cpu().numpy(), off)
+    m0 = int(oc[0])
+    np.testing.assert_array_equal(rows2[:m0, 1:5].cpu().numpy(), ob[0, :m0].cpu().numpy())
+
+
+def _iou(a, b):
+    iw = np.maximum(0.0, np.minimum(a[2], b[:, 2]) - np.maximum(a[0], b[:, 0]))
+    ih = np.maximum(0.0, np.minimum(a[3], b[:, 3]) - np.maximum(a[1], b[:, 1]))
+    inter = iw * ih
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter)
+
+
+# stated bf16 tolerance (north_star "bf16 output within a stated tolerance"); measured values are in DESIGN.md section 2
+BF16_SCORE_TOL = 0.03       # |score difference| of matched detections (measured 0.015)
+BF16_MATCH_ALL = 0.80       # of ALL detections of one path, the share the other path reproduces with IoU >= 0.9 (measured 0.85 - 0.88)
+BF16_MATCH_CLEAR = 0.95     # of the detections scoring >= score_thresh + BF16_SCORE_TOL, the share reproduced with IoU >= 0.5
+
+
+def test_bf16_detections_vs_fp32_oracle(net_bf16, oracle, oracle_params):
+    """bf16 conv stack (bf16 storage + MFMA inputs, f32 accumulate) against the fp32 CPU oracle at the detection level,
+    2 x 416 x 416, gpu_nms defaults (50, 0.5, 0.5), both directions (oracle -> bf16 and bf16 -> oracle):
+      * a matched pair has the same class, IoU >= the bound and scores within BF16_SCORE_TOL;
+      * at least BF16_MATCH_ALL of all detections are matched at IoU >= 0.9.  The synthetic random-init weights put
+        most of the ~300 detections per image just above the 0.5 threshold, so a score change of 0.01 - 0.03 moves some
+        across it and flips some greedy NMS choices between near-identical overlapping boxes: those are the unmatched ones;
+      * of the detections that clear the threshold by more than the score tolerance at least BF16_MATCH_CLEAR are matched
+        at the usual detection criterion IoU >= 0.5."""
+    thr = 0.5
+    img = np.random.default_rng(1).random((2, 416, 416, 3), dtype=np.float32)
+    ob, osc, ol, _, oc = [t.cpu().numpy() for t in net_bf16.detect(img, 50, thr, 0.5)]
+    worst = {"all@0.9": 1.0, "clear@0.5": 1.0, "dscore": 0.0}
+    for b in range(2):
+        rb, rs, rl = oracle.detect(oracle_params, oracle.YOLO_ANCHORS, img[b:b + 1], 80, 50, thr, 0.5)
+        m = int(oc[b])
+        gb, gs, gl = ob[b, :m], osc[b, :m], ol[b, :m]
+        assert len(rl) > 20 and m > 20
+
+        def matched(ab, as_, al, bb, bs, bl, iou_min, only_clear):
+            hit, n, dmax = 0, 0, 0.0
+            for i in range(len(al)):
+                if only_clear and as_[i] < thr + BF16_SCORE_TOL:
+                    continue
+                n += 1
+                cand = np.nonzero(bl == al[i])[0]
+                if len(cand) == 0:
+                    continue
+                iou = _iou(ab[i], bb[cand])
+                j = int(np.argmax(iou))
+                d = abs(float(bs[cand[j]]) - float(as_[i]))
+                if iou[j] >= iou_min and d <= BF16_SCORE_TOL:
+                    hit += 1
+                    dmax = max(dmax, d)
+            return hit / max(1, n), dmax, n
+        for (A, Bq) in (((rb, rs, rl), (gb, gs, gl)), ((gb, gs, gl), (rb, rs, rl))):
+            f9, d1, _ = matched(*A, *Bq, 0.9, False)
+            f5, d2, nclear = matched(*A, *Bq, 0.5, True)
+            assert nclear > 20
+            worst["all@0.9"], worst["clear@0.5"] = min(worst["all@0.9"], f9), min(worst["clear@0.5"], f5)
+            worst["dscore"] = max(worst["dscore"], d1, d2)
+        print("image %d: oracle %d detections, bf16 %d" % (b, len(rl), m))
+    print("bf16 vs fp32 oracle detections:", worst)
+    assert worst["all@0.9"] >= BF16_MATCH_ALL and worst["clear@0.5"] >= BF16_MATCH_CLEAR, worst
+
+
+def test_pipeline_shape_change_with_pending_work(net_bf16):
+    """DetectPipeline.run twice with different frame shapes while the compute stream still has work queued: the staging
+    buffers are re-allocated, and the first copy into a new buffer is ordered behind everything the compute stream
+    has been given (the caching allocator may hand back a block those kernels still read)."""
+    import torch
+    from yolo_amd.pipeline import DetectPipeline
+    from yolo_amd.preprocess import preprocess
+    rng = np.random.default_rng(5)
+    pipe = DetectPipeline(net_bf16, (96, 96), 20, 0.02, 0.45)
+    a = [rng.integers(0, 256, (4, 120, 160, 3), dtype=np.uint8) for _ in range(3)]
+    b = [rng.integers(0, 256, (2, 64, 80, 3), dtype=np.uint8) for _ in range(3)]
+    big = torch.from_numpy(rng.random((16, 416, 416, 3), dtype=np.float32)).cuda()
+    got_a = [[t.clone() for t in o] for o in pipe.run(a)]
+    net_bf16.detect(big, 20, 0.5, 0.5)                               # several ms of queued compute-stream work ...
+    got_b = [[t.clone() for t in o] for o in pipe.run(b)]            # ... while the slots are re-allocated for a new shape
+    for frames, got in zip(a + b, got_a + got_b):
+        ref = net_bf16.detect(preprocess(frames, (96, 96)), 20, 0.02, 0.45)
+        cnt = ref[4].cpu().numpy()
+        assert torch.equal(got[4], ref[4])
+        for i in range(len(cnt)):
+            for j in range(4):
+                assert torch.equal(got[j][i, :cnt[i]], ref[j][i, :cnt[i]])

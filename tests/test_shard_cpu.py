@@ -123,3 +123,39 @@ def test_convert_weight_checkpoint_roundtrip(tmp_path, weight_stream):
         weights.state_to_stream(bad, 80)
     with pytest.raises(ValueError):
         convert_weight.convert(wf, ck, 20)
+
+
+def _rows_worker(rank, world, port, n_images, tmp):
+    """all_gather_rows: every rank packs ITS shard's detections as rows (image index first), the gathered list is the
+    row list of the whole batch in image order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yolo_amd.shard import all_gather_rows, shard_bounds
+        g = torch.Generator().manual_seed(11)
+        counts = torch.randint(0, 6, (n_images,), generator=g, dtype=torch.int32)
+        counts[0] = 0
+        off = torch.zeros(n_images + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        rows = torch.rand((int(off[-1]), 7), generator=g)
+        for i in range(n_images):
+            rows[off[i]:off[i + 1], 0] = i
+        lo, hi = shard_bounds(n_images, rank, world)
+        local = rows[off[lo]:off[hi]].clone()
+        local_off = (off[lo:hi + 1] - off[lo]).to(torch.int32)
+        got_rows, got_off = all_gather_rows(local, local_off, n_images)
+        assert torch.equal(got_rows, rows) and torch.equal(got_off, off)
+        open(os.path.join(tmp, "rows_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [9, 2])
+def test_all_gather_rows_gloo_world2(tmp_path, n_images):
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000) + n_images
+    mp.spawn(_rows_worker, args=(2, port, n_images, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "rows_ok0").exists() and (tmp_path / "rows_ok1").exists()

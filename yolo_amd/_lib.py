@@ -48,6 +48,7 @@ SIGNATURES = {
     "yolo_detect_post": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "yolo_nms_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "yolo_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "yolo_pack_detections": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "yolo_nms_static": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -507,6 +507,7 @@ static int post_run(DecodeK k, int B, int max_boxes, float st, float it, float* 
 
 extern "C" size_t yolo_nms_workspace_bytes(int B, int n, int class_num, int max_boxes) {
     if (B <= 0 || n <= 0 || class_num <= 0 || max_boxes <= 0) return 0;
+    if (max_boxes > yolo::kSelCap || class_num > 4096 || B > 65535) return 0;      // the limits yolo_nms enforces
     return yolo::nms_layout(nullptr, B, n, class_num, max_boxes).total;
 }
 
@@ -583,10 +584,77 @@ extern "C" int yolo_nms_static(const float* boxes, const float* scores, int B, i
                                 out_labels, out_index, out_counts, w, (hipStream_t)stream);
 }
 
+// ---- detections -> wire rows -------------------------------------------------------------------------
+// The step after gpu_nms in the reference's drivers: boxes back to the original image's pixels
+// (yolo_v3/test_single_image.py:42-45, video_test.py:67-71: boxes_[:, 0|2] *= width_ori / new_w, [:, 1|3] *= height_ori / new_h,
+// a float32 multiply by the float32-rounded ratio) and one dense list for the whole batch, rows
+// (image index, x0, y0, x1, y1, score, label) in image order - the format the shards of a multi-GPU run gather.
+namespace yolo {
+__global__ __launch_bounds__(256) void pack_offsets_kernel(const int* __restrict__ counts, int B, int cap, int* __restrict__ offsets) {
+    __shared__ int part[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) { carry = 0; offsets[0] = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 256) {                      // blocked inclusive scan, 256 images at a time
+        const int b = b0 + threadIdx.x;
+        int c = b < B ? counts[b] : 0;
+        c = c < 0 ? 0 : (c > cap ? cap : c);
+        part[threadIdx.x] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (b < B) offsets[b + 1] = carry + part[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                        const int* __restrict__ labels, const int* __restrict__ offsets, int cap,
+                                                        const float* __restrict__ scale_xy, int image_base, float* __restrict__ rows) {
+    const int b = blockIdx.x;
+    const int lo = offsets[b], m = offsets[b + 1] - lo;
+    const float sx = scale_xy ? scale_xy[2 * b] : 1.0f, sy = scale_xy ? scale_xy[2 * b + 1] : 1.0f;
+    for (int r = threadIdx.x; r < m; r += 256) {
+        const long long src = (long long)b * cap + r;
+        const f32x4 bx = ((const f32x4*)boxes)[src];
+        float* o = rows + (long long)(lo + r) * 7;
+        o[0] = (float)(image_base + b);
+        o[1] = scale_xy ? __fmul_rn(bx[0], sx) : bx[0];
+        o[2] = scale_xy ? __fmul_rn(bx[1], sy) : bx[1];
+        o[3] = scale_xy ? __fmul_rn(bx[2], sx) : bx[2];
+        o[4] = scale_xy ? __fmul_rn(bx[3], sy) : bx[3];
+        o[5] = scores[src];
+        o[6] = (float)labels[src];
+    }
+}
+}  // namespace yolo
+
+extern "C" int yolo_pack_detections(const float* boxes, const float* scores, const int32_t* labels, const int32_t* counts, int B,
+                                    int cap, const float* scale_xy, int image_base, float* rows, int32_t* offsets, void* stream) {
+    using namespace yolo;
+    YOLO_REQUIRE(boxes && scores && labels && counts && rows && offsets, YOLO_ERR_ARG, "pack_detections: null pointer");
+    YOLO_REQUIRE(B > 0 && cap > 0 && B <= (1 << 20) && image_base >= 0, YOLO_ERR_ARG, "pack_detections: bad size");
+    YOLO_REQUIRE((long long)B * cap < (1ll << 31) / 8 && (long long)image_base + B < (1 << 24), YOLO_ERR_SHAPE,
+                 "pack_detections: problem too large (image indices are carried as float32)");
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, B, cap, offsets);
+    YOLO_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, boxes, scores, labels, offsets, cap,
+                       scale_xy, image_base, rows);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
 static int post_shape(int H, int W) { return 3 * ((H / 32) * (W / 32) + (H / 16) * (W / 16) + (H / 8) * (W / 8)); }
 
 extern "C" size_t yolo_detect_post_workspace_bytes(int B, int H, int W, int class_num, int max_boxes) {
     if (B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32 || class_num <= 0 || max_boxes <= 0) return 0;
+    if (max_boxes > yolo::kSelCap || class_num > 250 || B > 65535) return 0;       // the limits yolo_detect_post enforces
     return yolo::post_layout(nullptr, B, post_shape(H, W), class_num, max_boxes).total;
 }
 

@@ -33,7 +33,14 @@ class DetectPipeline(object):
             if self._copied[k] is not None:
                 self._copied[k].synchronize()
             self._pinned[k] = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            old_consumed = self._consumed[k]
             self._dev[k] = torch.empty(shape, dtype=torch.uint8, device=_tensor.device())
+            # the caching allocator may hand back a block that kernels already enqueued on the compute stream still read
+            # (a just-freed preprocess / detect tensor, the previous buffer of this slot): the first copy into the new
+            # buffer must order after all of them
+            self._copy_stream.wait_stream(torch.cuda.current_stream())
+            if old_consumed is not None:
+                self._copy_stream.wait_event(old_consumed)
             self._copied[k] = torch.cuda.Event()
             self._consumed[k] = None
 

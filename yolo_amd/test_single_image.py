@@ -14,6 +14,7 @@ import numpy as np
 
 from .model import yolov3
 from .preprocess import preprocess
+from .shard import pack_detections_device
 from .utils.misc_utils import DEFAULT_ANCHORS, parse_anchors, read_class_names
 
 
@@ -32,16 +33,15 @@ def detect_frames(yolo_model, frames, new_size=(416, 416), max_boxes=30, score_t
     height_ori, width_ori = int(frames.shape[1]), int(frames.shape[2])
     img = preprocess(frames, new_size)                                                    # :25-28
     ob, osc, ol, _, oc = yolo_model.detect(img, max_boxes, score_thresh, iou_thresh)      # :31-40
-    ob, osc, ol, oc = ob.cpu().numpy(), osc.cpu().numpy(), ol.cpu().numpy(), oc.cpu().numpy()
+    # :42-45 on the GPU: boxes_[:, 0|2] *= width_ori / new_w, boxes_[:, 1|3] *= height_ori / new_h (float32 multiplies)
+    B = int(ob.shape[0])
+    scale = np.tile(np.asarray([width_ori / float(new_size[0]), height_ori / float(new_size[1])], np.float32), (B, 1))
+    rows, offsets = pack_detections_device(ob, osc, ol, oc, scale)
+    rows, offsets = rows.cpu().numpy(), offsets.cpu().numpy()
     out = []
-    for b in range(ob.shape[0]):
-        m = int(oc[b])
-        boxes_, scores_, labels_ = ob[b, :m].copy(), osc[b, :m].copy(), ol[b, :m].copy()
-        boxes_[:, 0] *= (width_ori / float(new_size[0]))                                  # :42-45
-        boxes_[:, 2] *= (width_ori / float(new_size[0]))
-        boxes_[:, 1] *= (height_ori / float(new_size[1]))
-        boxes_[:, 3] *= (height_ori / float(new_size[1]))
-        out.append((boxes_, scores_, labels_))
+    for b in range(B):
+        r = rows[offsets[b]:offsets[b + 1]]
+        out.append((r[:, 1:5].copy(), r[:, 5].copy(), r[:, 6].astype(np.int32)))
     return out
 
 
