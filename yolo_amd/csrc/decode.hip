@@ -40,6 +40,65 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeK k) {
     }
 }
 
+// ---- predict at the HBM rate: one workgroup per tile of kDecTile boxes of one scale of one image ---------------------------------
+// The tile's logits are one contiguous run of kDecTile * (5 + C) floats: they are read once with coalesced loads into LDS,
+// the box conf is sigmoid-ed once per box, and every output tensor of the tile is again one contiguous run - probs / scores
+// (16-byte aligned: the row length C * 4 bytes times kDecTile boxes) go out as 16-byte stores, boxes as one float4 per box.
+// Arithmetic per element is exactly decode_kernel's (sigmoid_fast / decode_box_attr): same bits.
+constexpr int kDecTile = 64;
+
+__global__ __launch_bounds__(256) void decode_tile_kernel(DecodeK k, int tiles0, int tiles1) {
+    extern __shared__ float dlog[];                 // [kDecTile * A] logits, then [kDecTile] conf
+    const int b = blockIdx.y;
+    int t = blockIdx.x, s = 0;
+    if (t >= tiles0 + tiles1) { s = 2; t -= tiles0 + tiles1; }
+    else if (t >= tiles0) { s = 1; t -= tiles0; }
+    const int ns = k.off[s + 1] - k.off[s];
+    const int j0 = t * kDecTile;                    // first box of the tile inside its scale
+    const int nj = min(kDecTile, ns - j0);
+    const int A = k.A, C = k.C;
+    const float* src = k.fm[s] + ((long long)b * ns + j0) * A;
+    const int nel = nj * A;
+    for (int e = threadIdx.x; e < nel; e += 256) dlog[e] = src[e];
+    float* conf = dlog + kDecTile * A;
+    __syncthreads();
+    const long long jb = (long long)b * k.n + k.off[s] + j0;       // first box of the tile in the [B, n] outputs
+    if (threadIdx.x < nj) {
+        const int j = threadIdx.x;
+        const float* row = dlog + j * A;
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        f32x4 box;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) box[a] = decode_box_attr(k, s, j0 + j, row, a);       // model.py:76-108,147-152
+        ((f32x4*)k.boxes)[jb + j] = box;
+        const float cf = sigmoid_fast(row[4]);                                              // model.py:134
+        conf[j] = cf;
+        k.confs[jb + j] = cf;
+    }
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    const int nout = nj * C;                        // multiple of 4 when C % 4 == 0 (checked on the host)
+    f32x4* pp = (f32x4*)(k.probs + jb * C);
+    f32x4* sp = k.scores ? (f32x4*)(k.scores + jb * C) : nullptr;
+    const float inv_c = 1.0f / (float)C;
+    for (int q = threadIdx.x; q < nout / 4; q += 256) {
+        f32x4 pr, sc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * q + i;
+            int j = (int)((float)e * inv_c);        // e / C without an integer division, fixed up
+            int c = e - j * C;
+            if (c < 0) { c += C; --j; }
+            if (c >= C) { c -= C; ++j; }
+            const float p = sigmoid_fast(dlog[j * A + 5 + c]);                              // model.py:135
+            pr[i] = p;
+            sc[i] = conf[j] * p;                                                            // test_single_image.py:38
+        }
+        pp[q] = pr;
+        if (sp) sp[q] = sc;
+    }
+}
+
 }  // namespace yolo
 
 extern "C" int yolo_decode(const float* fm1, const float* fm2, const float* fm3, int B, int H, int W, int class_num,
@@ -54,6 +113,24 @@ extern "C" int yolo_decode(const float* fm1, const float* fm2, const float* fm3,
     decode_setup(k, H, W, class_num, anchors);
     const long long per_img = (long long)k.n * k.A;
     YOLO_REQUIRE(per_img < (1ll << 24), YOLO_ERR_SHAPE, "decode: more than 2^24 elements per image");
+    const size_t lds = (size_t)(kDecTile * k.A + kDecTile) * sizeof(float);
+    if (class_num % 4 == 0 && lds <= 64 * 1024 && ((uintptr_t)probs & 15) == 0 && ((uintptr_t)scores & 15) == 0 &&
+        ((uintptr_t)boxes & 15) == 0) {
+        // tiled kernel (16-byte stores need C % 4 == 0; COCO 80 / VOC 20 both qualify)
+        int tiles[3];
+        for (int s = 0; s < 3; ++s) tiles[s] = (k.off[s + 1] - k.off[s] + kDecTile - 1) / kDecTile;
+        static bool attr_done[16] = {false};
+        int dev = 0;
+        YOLO_HIP_CHECK(hipGetDevice(&dev));
+        if (dev >= 16 || !attr_done[dev]) {
+            YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)decode_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            if (dev < 16) attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL(decode_tile_kernel, dim3((unsigned)(tiles[0] + tiles[1] + tiles[2]), B), dim3(256), lds, (hipStream_t)stream,
+                           k, tiles[0], tiles[1]);
+        YOLO_HIP_CHECK(hipGetLastError());
+        return YOLO_OK;
+    }
     unsigned gx = (unsigned)((per_img + 255) / 256);
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(decode_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, k);
