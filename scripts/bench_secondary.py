@@ -3,7 +3,8 @@
 
   config 4: YOLOv2-416 VOC-20, batch 64: build_networks (bf16 conv stack) + decode + class-agnostic NMS (0.3 / 0.5)
   config 5: NMS stress, 608 x 608 decode shape: 8 images x 22743 boxes x 80 classes, score_thresh 0.001, iou 0.5, 50 per class,
-            plain and "clustered" (200 seed boxes x jitter N(0, 4 px)) box sets
+            plain and "clustered" (200 seed boxes x jitter N(0, 4 px)) box sets; and the whole chain (forward + predict + NMS)
+            at 608 x 608, batch 8, with that threshold
 
 python scripts/bench_secondary.py [--steps 20] [--warmup 5]"""
 import argparse
@@ -97,6 +98,23 @@ def config5(steps, warmup, B=8):
     return out
 
 
+def config5_e2e(steps, warmup, B=8):
+    """Config 5 widened: the whole chain at 608 x 608 with the eval-style threshold (model.py:22: the size comes from the
+    input; eval.py:93-95 passes score_thresh through gpu_nms): forward + predict + conf*prob + per-class NMS in one call."""
+    from yolo_amd.model import yolov3
+    from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
+    from yolo_amd.weights import synth_darknet_stream
+    net = yolov3(80, DEFAULT_ANCHORS, dtype="bf16").load_weight_stream(synth_darknet_stream(80, seed=1234))
+    x = torch.from_numpy(np.random.default_rng(5).random((B, 608, 608, 3), dtype=np.float32)).cuda()
+    dt = timed(lambda: net.detect(x, 50, 0.001, 0.5), steps, warmup)
+    fwd = timed(lambda: net.forward(x), steps, warmup)
+    cnt = net.detect(x, 50, 0.001, 0.5)[4]
+    return {"config": 5, "variant": "end_to_end_608", "metric": "YOLOv3-608 images/sec end-to-end (conv + decode + NMS), score_thresh 0.001, "
+            "max_boxes 50, batch %d" % B, "value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 4), "dtype": "bf16",
+            "conv_stack_ms": round(fwd * 1e3, 4), "conv_stack_tflops": round(140.692e9 * B / fwd / 1e12, 1),
+            "kept_last_step": int(cnt.sum().item()), "data": "synthetic"}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -106,3 +124,4 @@ if __name__ == "__main__":
     print(json.dumps(config4(a.steps, a.warmup)))
     for line in config5(a.steps, a.warmup):
         print(json.dumps(line))
+    print(json.dumps(config5_e2e(a.steps, a.warmup)))

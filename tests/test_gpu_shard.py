@@ -165,3 +165,35 @@ def test_pipeline_shape_change_with_pending_work(net_bf16):
         for i in range(len(cnt)):
             for j in range(4):
                 assert torch.equal(got[j][i, :cnt[i]], ref[j][i, :cnt[i]])
+
+
+def test_detect_batch8_608_eval_threshold_properties(net_bf16, oracle):
+    """BASELINE config 5 end to end: forward + predict + conf*prob + per-class NMS at 608 x 608 (model.py:22: the size comes
+    from the input), batch 8, score_thresh 0.001 / max_boxes 50 (the eval-style call of eval.py:93-95): 22743 boxes x 80
+    classes per image, nearly all of them candidates.  Size-independent properties: sub-batches give the same rows, every
+    class list is score-sorted and of length <= 50, and for a sample of (image, class) pairs the kept indices equal the
+    oracle's NMS run on the SAME decoded boxes / scores."""
+    import torch
+    x = torch.from_numpy(np.random.default_rng(6).random((8, 608, 608, 3), dtype=np.float32)).cuda()
+    ob, osc, ol, oi, oc = [t.clone() for t in net_bf16.detect(x, 50, 0.001, 0.5)]
+    cnt = oc.cpu().numpy()
+    assert net_bf16.img_size == (608, 608) and cnt.min() > 80 * 10 and cnt.max() <= 80 * 50
+    sb, ss, sl, si, sc = net_bf16.detect(x[5:7], 50, 0.001, 0.5)
+    assert torch.equal(sc, oc[5:7])
+    for j in range(2):
+        m = int(cnt[5 + j])
+        for a, b in ((sb, ob), (ss, osc), (sl, ol), (si, oi)):
+            assert torch.equal(a[j, :m], b[5 + j, :m])
+    fms = net_bf16.forward(x)
+    boxes, _, _, scores = net_bf16.predict(fms, return_scores=True)
+    assert tuple(boxes.shape) == (8, 22743, 4)
+    for b in (0, 7):
+        m = int(cnt[b])
+        ks, kl, ki = [t[b, :m].cpu().numpy() for t in (osc, ol, oi)]
+        assert np.all(np.diff(kl) >= 0) and np.all(ks >= np.float32(0.001))
+        bx, sx = boxes[b].cpu().numpy(), scores[b].cpu().numpy()
+        for c in (0, 33, 79):
+            sel = kl == c
+            assert np.all(ks[sel][:-1] >= ks[sel][1:]) and sel.sum() <= 50
+            ref = oracle.class_nms_c(bx, sx, c, 50, 0.001, 0.5, 0)
+            assert np.array_equal(ki[sel], ref), (b, c)
