@@ -159,3 +159,76 @@ def test_all_gather_rows_gloo_world2(tmp_path, n_images):
     port = 31500 + (os.getpid() % 2000) + n_images
     mp.spawn(_rows_worker, args=(2, port, n_images, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "rows_ok0").exists() and (tmp_path / "rows_ok1").exists()
+
+
+def test_cfg_parser_vs_reference_block_list():
+    """G6 = the block list the reference's own parse_cfg (yolo-v3/002/darknet.py:12-36) yields for its cfg/yolov3.cfg.
+    yolo_amd.cfg.parse_cfg reproduces it from the rendered text, and plan_from_blocks turns it into exactly the conv plan
+    the library hard-codes (75 convs, 9 COCO anchors, 80 classes); topologies the library does not execute are refused."""
+    import copy
+    import json
+    from conftest import GOLDEN
+    from yolo_amd import cfg, weights
+    from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
+    blocks = json.load(open(os.path.join(GOLDEN, "g6_yolov3_cfg_blocks.json")))
+    assert len(blocks) == 108
+    text = cfg.blocks_to_text(blocks)
+    assert cfg.parse_cfg("# comment\n\n  " + text.replace("=", " = ")) == blocks       # whitespace / comments as the reference handles them
+    plan = cfg.plan_from_blocks(blocks)
+    assert plan["class_num"] == 80 and (plan["width"], plan["height"]) == (320, 320)
+    np.testing.assert_array_equal(plan["anchors"], DEFAULT_ANCHORS)
+    want = weights.yolov3_conv_specs(80)
+    assert [(s["cin"], s["cout"], s["k"], s["stride"], s["bn"]) for s in plan["specs"]] == \
+           [(s["cin"], s["cout"], s["k"], s["stride"], s["bn"]) for s in want]
+    assert [s["block"] for s in plan["specs"]][-1] == 105 and plan["specs"][58]["block"] == 81      # the three pre-yolo convs: 81 / 93 / 105
+    ref_cfg = "/root/reference/yolo-v3/002/cfg/yolov3.cfg"
+    if os.path.exists(ref_cfg):                                                        # build container only
+        assert cfg.parse_cfg(ref_cfg) == blocks
+    # a 20-class variant is accepted (filters of the three detection convs follow the class count) ...
+    voc = copy.deepcopy(blocks)
+    for i, b in enumerate(voc):
+        if b["type"] == "yolo":
+            b["classes"] = "20"
+            voc[i - 1]["filters"] = "75"
+    assert cfg.plan_from_blocks(voc)["class_num"] == 20
+    # ... other topologies are not
+    bad = copy.deepcopy(blocks)
+    bad[3]["filters"] = "48"
+    with pytest.raises(ValueError):
+        cfg.plan_from_blocks(bad)
+    bad = copy.deepcopy(blocks)
+    bad[5]["from"] = "-2"
+    with pytest.raises(ValueError):
+        cfg.plan_from_blocks(bad)
+    with pytest.raises(ValueError):
+        cfg.parse_cfg("[net]\nwidth 416\n")
+
+
+def test_yolov2_darknet_stream_to_variables():
+    """A Darknet-order yolov2 stream ([beta, gamma, mean, var | bias] + OIHW kernel per conv) maps onto the TF variable
+    stream of the reference's graph: same convolution (oracle conv_layer on both parameterisations)."""
+    from oracle import yolo2_oracle as O2
+    from yolo_amd.yolo_v2.yolo import yolo_v2 as Y
+    rng = np.random.default_rng(3)
+    shapes = Y.conv_shapes(20, 5)
+    parts = []
+    for name, (k, _, ci, co), bn in shapes:
+        if bn:
+            parts += [rng.normal(0, 0.1, co), rng.uniform(0.5, 1.5, co), rng.normal(0, 0.1, co), rng.uniform(0.5, 1.5, co)]
+        else:
+            parts.append(rng.normal(0, 0.1, co))
+        parts.append(rng.normal(0, 0.05, (co, ci, k, k)).ravel())
+    stream = np.concatenate(parts).astype(np.float32)
+    var = Y.split_variables(Y.darknet_stream_to_variables(stream, 20, 5), 20, 5)
+    # first conv: Darknet order beta, gamma, mean, var, kernel OIHW
+    c0 = var["0_conv"]
+    assert np.array_equal(c0["shift"], stream[:32]) and np.array_equal(c0["scale"], stream[32:64])
+    assert np.array_equal(c0["rolling_mean"], stream[64:96]) and np.array_equal(c0["rolling_variance"], stream[96:128])
+    assert np.all(c0["biases"] == 0)
+    k0 = stream[128:128 + 32 * 27].reshape(32, 3, 3, 3)
+    assert np.array_equal(c0["weight"], np.transpose(k0, (2, 3, 1, 0)))
+    last = var["30_conv"]
+    assert last["weight"].shape == (1, 1, 1024, 125) and np.array_equal(last["biases"], stream[-125 - 1024 * 125:-1024 * 125])
+    with pytest.raises(ValueError):
+        Y.darknet_stream_to_variables(stream[:-1], 20, 5)
+    del O2

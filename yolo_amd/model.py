@@ -31,6 +31,18 @@ class yolov3(object):
         self._det_ws = None
         self.img_size = None
 
+    @classmethod
+    def from_cfg(cls, cfgfile, weights_file=None, dtype="fp32"):
+        """Darknet-style construction (yolo-v3/002/darknet.py:150-153 `Darknet(cfgfile)` + `load_weights`): class count and
+        anchors come from the .cfg, which must describe the YOLOv3 topology (yolo_amd/cfg.py); `net_size` = (width, height)."""
+        from . import cfg as _cfg
+        plan = _cfg.load_cfg(cfgfile)
+        m = cls(plan["class_num"], plan["anchors"], dtype=dtype)
+        m.net_size = (plan["width"], plan["height"])
+        if weights_file is not None:
+            m.load_darknet_weights(weights_file)
+        return m
+
     # ---- weights (replaces tf.train.Saver.restore at test_single_image.py:35-36) -----------------
     def load_weight_stream(self, stream):
         """stream: float32 body of a Darknet .weights file (conv order = call order of forward)."""

@@ -46,6 +46,36 @@ def split_variables(stream, num_class=len(cfg.CLASSES), box_per_cell=cfg.BOX_PRE
     return out
 
 
+def darknet_stream_to_variables(stream, num_class=len(cfg.CLASSES), box_per_cell=cfg.BOX_PRE_CELL):
+    """Float32 body of a Darknet yolov2 `.weights` file (after the header; e.g. yolov2-voc.weights) -> the TF variable stream
+    `load_variables` / yolo2_net_create take.  Darknet stores, per conv in cfg order (= the call order of build_networks:
+    the 22 trunk convs, the passthrough 1x1 conv, the two head convs), [biases, scales, rolling_mean, rolling_variance]
+    (batch-norm convs) or [biases], then the kernel as [Cout, Cin, kh, kw] - the layout of yolo_v3/utils/misc_utils.py:45-96
+    and yolo-v3/002/darknet.py:212-265.  The reference's conv_layer (yolo_v2.py:75-86) has BOTH a BN shift and an extra
+    `biases` variable; Darknet has one: it becomes `shift`, `biases` is zero.  (The reference's reorg channel order,
+    yolo_v2.py:108-112, is its own: a Darknet-trained passthrough layer keeps Darknet's order, which this build does not
+    reproduce - load such weights for the trunk, not for bit-parity with Darknet's yolov2.)"""
+    stream = np.asarray(stream, np.float32)
+    parts, ptr = [], 0
+    for name, (k, _, ci, co), bn in conv_shapes(num_class, box_per_cell):
+        nb = 4 * co if bn else co
+        if ptr + nb + k * k * ci * co > stream.size:
+            raise ValueError("Darknet stream too short at %s" % name)
+        head = stream[ptr:ptr + nb]
+        ptr += nb
+        w = stream[ptr:ptr + co * ci * k * k].reshape(co, ci, k, k)
+        ptr += co * ci * k * k
+        parts.append(np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0))).ravel())        # OIHW -> HWIO
+        if bn:
+            beta, gamma, mean, var = head[:co], head[co:2 * co], head[2 * co:3 * co], head[3 * co:]
+            parts += [np.zeros(co, np.float32), gamma, beta, mean, var]                   # biases, scale, shift, mean, variance
+        else:
+            parts.append(head)
+    if ptr != stream.size:
+        raise ValueError("Darknet stream has %d floats, the architecture needs %d" % (stream.size, ptr))
+    return np.concatenate(parts).astype(np.float32)
+
+
 class yolo_v2(object):
 
     def __init__(self, isTraining=True, dtype="fp32"):
