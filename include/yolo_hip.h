@@ -201,6 +201,8 @@ int yolo_reorg2x(const float* in, int B, int H, int W, int C, float* out, void* 
  * input pixels, probs float32 = softmax(classes) * sigmoid(conf), exactly the reference's numpy dtypes. */
 int yolo2_decode(const float* logits, int B, int S, int NB, int C, int image_size, const double* anchors,
                  double* boxes, float* probs, void* stream);
+/* yolo2_nms: out_counts[i] <= max_det is the number of rows written for image i; max_det + 1 means more detections survived
+ * than rows were given (the reference has no cap: call again with max_det = n * C, which always suffices). */
 size_t yolo2_nms_workspace_bytes(int B, int n, int C);
 int yolo2_nms(const double* boxes, const float* probs, int B, int n, int C, float threshold, double iou_thresh,
               int max_det, int32_t* out_counts, int32_t* out_cls, double* out_boxes, float* out_probs,

@@ -238,3 +238,31 @@ def test_detect_resizes_uint8_images_on_gpu(detector, v2_f32):
         assert g[3] == r[3] * (1.0 * 500 / 416) and g[4] == r[4] * (1.0 * 300 / 416)
     with pytest.raises(ValueError):
         detector.detect(np.zeros((300, 500, 3), np.float32))
+
+
+def test_nms_degenerate_boxes_survive_in_several_classes(detector, O2):
+    """A zero-size box has IoU 0/0 = NaN with itself, and `NaN > 0.5` is false (Detector.py:76, :107-115): every class of
+    it that passes the threshold survives, as in the reference, so one box can give several rows.  With the default of
+    n rows that can overflow: the kernel reports max_det + 1 and calc_output_batched repeats with n * C rows."""
+    import warnings
+    rng = np.random.default_rng(19)
+    S, NB, C = 13, 5, 20
+    boxes = np.zeros((1, S, S, NB, 4), np.float64)
+    boxes[..., :2] = rng.random((1, S, S, NB, 2)) * 416
+    boxes[..., 2:] = 0.0                                                 # every box degenerate
+    probs = np.zeros((1, S, S, NB, C), np.float32)
+    probs[0, :, :, :, 3] = 0.6
+    probs[0, :, :, :, 11] = 0.5                                          # two classes per box pass -> 2 n survivors
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                   # the oracle divides 0 by 0 like the reference
+        rc, rb, rp, rf = O2.nms_from_decoded(boxes[0], probs[0])
+    n = S * S * NB
+    assert len(rc) == 2 * n
+    counts, cls, ob, op, flat = detector.nms(boxes, probs)               # default n rows: cut, and reported as cut
+    assert int(counts[0]) == n + 1
+    counts, cls, ob, op, flat = detector.nms(boxes, probs, n * C)
+    m = int(counts[0])
+    assert m == 2 * n
+    np.testing.assert_array_equal(flat[0, :m].cpu().numpy(), rf)
+    np.testing.assert_array_equal(cls[0, :m].cpu().numpy(), rc)
+    np.testing.assert_array_equal(op[0, :m].cpu().numpy(), rp)

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void nms2_kernel(const double* __restrict__ bo
     bool have = false;
     u64 selkey = 0;
     double sb[4] = {0, 0, 0, 0};
-    while (ndet < max_det) {
+    bool truncated = false;
+    while (true) {
         u64 best = kDead2;
         for (int i = tid; i < k; i += 256) {
             const u64 key = keys[i];
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void nms2_kernel(const double* __restrict__ bo
         __syncthreads();
         selkey = bcast;
         if (selkey == kDead2) break;
+        if (ndet == max_det) { truncated = true; break; }      // a survivor that has no output row left
         const unsigned f = ~(unsigned)selkey;
         const int box = (int)(f / C);
         for (int e = 0; e < 4; ++e) sb[e] = bx[(long long)box * 4 + e];
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(256) void nms2_kernel(const double* __restrict__ bo
         }
         ++ndet;
     }
-    if (tid == 0) out_count[b] = ndet;
+    // degenerate boxes (w*h == 0, inf, NaN: IoU is NaN, never > thr) let several classes of ONE box survive, so n rows are
+    // not a bound; the reference (Detector.py:72-83) has no cap: a count of max_det + 1 tells the caller rows were cut
+    if (tid == 0) out_count[b] = truncated ? max_det + 1 : ndet;
 }
 
 }  // namespace yolo

@@ -29,6 +29,7 @@ class yolov3(object):
         self._ws = None
         self._post_ws = None
         self._det_ws = None
+        self._device = None
         self.img_size = None
 
     @classmethod
@@ -53,7 +54,19 @@ class yolov3(object):
         _lib.check(_lib.lib().yolo_net_create(self.class_num, self._dtype_code, stream.ctypes.data,
                                               stream.size, ctypes.byref(h)))
         self._net = h
+        self._device = torch.cuda.current_device()               # the packed weights live on this GPU
         return self
+
+    def _check_ready(self, x):
+        """Shared argument validation of forward / forward_timed / detect: weights loaded, NHWC 3-channel input, and the
+        current GPU is the one that holds the weights (a launch on another device would read them through peer access or fault)."""
+        if self._net is None:
+            raise RuntimeError("weights not loaded: call load_darknet_weights()/load_weight_stream() first")
+        if torch.cuda.current_device() != self._device:
+            raise RuntimeError("yolov3 weights were loaded on cuda:%d but the current device is cuda:%d"
+                               % (self._device, torch.cuda.current_device()))
+        if x is not None and (x.dim() != 4 or x.shape[3] != 3):
+            raise ValueError("inputs must be [N, H, W, 3], got %s" % (tuple(x.shape),))
 
     def load_darknet_weights(self, weights_file):
         return self.load_weight_stream(misc_utils.read_darknet_weights(weights_file))
@@ -83,11 +96,8 @@ class yolov3(object):
     def forward(self, inputs, is_training=False, reuse=False):
         if is_training:
             raise ValueError("yolo_amd implements the inference path only (is_training=False)")
-        if self._net is None:
-            raise RuntimeError("weights not loaded: call load_darknet_weights()/load_weight_stream() first")
-        x = _tensor.as_dev_f32(inputs)
-        if x.dim() != 4 or x.shape[3] != 3:
-            raise ValueError("inputs must be [N, H, W, 3], got %s" % (tuple(x.shape),))
+        x = _tensor.as_dev_f32(inputs) if self._net is not None else None
+        self._check_ready(x)
         B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
         self.img_size = (H, W)                                   # model.py:22
         L = _lib.lib()
@@ -105,12 +115,15 @@ class yolov3(object):
     def forward_timed(self, inputs):
         """Measurement aid: forward with per-layer hipEvent timing -> (fms, ms[75], [(cin,cout,k,stride)]);
         `self.layer_kernels` then holds the kernel instantiation launched for every layer."""
-        x = _tensor.as_dev_f32(inputs)
+        x = _tensor.as_dev_f32(inputs) if self._net is not None else None
+        self._check_ready(x)
         B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
         self.img_size = (H, W)
         L = _lib.lib()
         need = L.yolo_net_workspace_bytes(self._net, B, H, W)
-        if self._ws is None or self._ws.numel() < need:
+        if need == 0:
+            raise ValueError("unsupported input shape %s (H, W must be multiples of 32)" % (tuple(x.shape),))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = _tensor.workspace(need)
         nout = 3 * (5 + self.class_num)
         fms = [_tensor.empty((B, H // r, W // r, nout)) for r in (32, 16, 8)]
@@ -134,11 +147,8 @@ class yolov3(object):
         ONE library call (yolo_net_detect): identical results to postprocess(forward(inputs)) and to the
         reference's separate calls (detect_unfused), without the [N,n,C] probs / scores tensors; the feature maps
         stay in the workspace and every lane post-processes its own images."""
-        if self._net is None:
-            raise RuntimeError("weights not loaded: call load_darknet_weights()/load_weight_stream() first")
-        x = _tensor.as_dev_f32(inputs)
-        if x.dim() != 4 or x.shape[3] != 3:
-            raise ValueError("inputs must be [N, H, W, 3], got %s" % (tuple(x.shape),))
+        x = _tensor.as_dev_f32(inputs) if self._net is not None else None
+        self._check_ready(x)
         B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
         self.img_size = (H, W)
         C = self.class_num

@@ -83,7 +83,10 @@ class Detector(object):
         bx = bx.to(device=_tensor.device(), dtype=torch.float64).contiguous().reshape(-1, n, 4)
         pr = _tensor.as_dev_f32(probs).reshape(-1, n, C)
         B = int(pr.shape[0])
-        # at most one survivor per box (same box -> IoU 1 > 0.5), so n rows always suffice
+        # normally at most one survivor per box (same box -> IoU 1 > 0.5): n rows.  Degenerate boxes (zero area, inf / NaN
+        # from an exp overflow) have IoU NaN with themselves, so several classes of one box can survive as they do in the
+        # reference (Detector.py:72-83, no cap): counts[i] == max_det + 1 reports that rows were cut (calc_output_batched
+        # then repeats the call with n * C rows, which always suffice)
         max_det = int(max_det or n)
         L = _lib.lib()
         counts = _tensor.empty((B,), torch.int32)
@@ -107,6 +110,8 @@ class Detector(object):
         """Per-image calc_output for a batch of logits -> list (per image) of result lists."""
         boxes, probs = self.decode(output)
         counts, cls, ob, op, _ = self.nms(boxes, probs)
+        if int(counts.max().item()) > int(cls.shape[1]):                          # truncated: the reference has no cap
+            counts, cls, ob, op, _ = self.nms(boxes, probs, self.cell_size * self.cell_size * self.box_per_cell * self.num_classes)
         counts, cls, ob, op = counts.cpu().numpy(), cls.cpu().numpy(), ob.cpu().numpy(), op.cpu().numpy()
         out = []
         for b in range(len(counts)):
