@@ -1,5 +1,6 @@
 // Shared host-side helpers for libyolo_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdint>

@@ -1159,7 +1159,7 @@ static int launch_p8(const ConvK& k, hipStream_t stream) {
     YOLO_REQUIRE(k.Cout % 256 == 0, YOLO_ERR_UNSUPPORTED, "conv3x3 p8: Cout=%d not a multiple of 256", k.Cout);
     YOLO_REQUIRE((long long)k.M * k.in_ld * 2 < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 p8: input larger than 4 GiB");
     auto fn = conv3x3_p8_kernel<MT>;
-    static bool attr_done[16] = {false};
+    static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 16 || !attr_done[dev]) {
@@ -1187,7 +1187,7 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 halo: W=%d needs %d bytes of LDS", k.W, lds_bytes);
     YOLO_REQUIRE((long long)k.M * k.in_ld * (BF16 ? 2 : 4) < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 halo: input larger than 4 GiB");
     auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB, MS, EPASS, MINW>;
-    static bool attr_done[16] = {false};
+    static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 16 || !attr_done[dev]) {
@@ -1214,7 +1214,7 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     if (EPASS == 0 || EPASS == 3) YOLO_REQUIRE(!k.upsample && !k.reorg && !k.out_f32, YOLO_ERR_UNSUPPORTED, "conv: wave epilogue on a scatter / f32-head layer");
     auto fn = conv_igemm_kernel<BF16, BM, BN, WARPS_M, WARPS_N, STAGES, MS, EPASS, MINW>;
-    static bool attr_done[16] = {false};
+    static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 16 || !attr_done[dev]) {

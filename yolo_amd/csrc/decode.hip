@@ -119,7 +119,7 @@ extern "C" int yolo_decode(const float* fm1, const float* fm2, const float* fm3,
         // tiled kernel (16-byte stores need C % 4 == 0; COCO 80 / VOC 20 both qualify)
         int tiles[3];
         for (int s = 0; s < 3; ++s) tiles[s] = (k.off[s + 1] - k.off[s] + kDecTile - 1) / kDecTile;
-        static bool attr_done[16] = {false};
+        static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
         int dev = 0;
         YOLO_HIP_CHECK(hipGetDevice(&dev));
         if (dev >= 16 || !attr_done[dev]) {

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
 
 template <int TH>
 static int launch_front_th(const FrontK& k, int grid, int act_mode, hipStream_t stream) {
-    static bool attr_done[16] = {false};
+    static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 16 || !attr_done[dev]) {

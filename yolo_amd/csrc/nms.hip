@@ -480,7 +480,7 @@ static int post_run(DecodeK k, int B, int max_boxes, float st, float it, float* 
     const unsigned tiles = (unsigned)((n + kTileJ - 1) / kTileJ);
     const size_t lds = (size_t)kTileJ * (k.A | 1) * 4;
     auto fn = decode_compact_kernel<YOLO_NMS_TF>;
-    static bool attr_done[16] = {false};
+    static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 16 || !attr_done[dev]) {

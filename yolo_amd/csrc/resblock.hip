@@ -242,7 +242,7 @@ int launch_res_block(const ConvLaunch& c1, const ConvLaunch& c3, hipStream_t str
     k.ntiles = (int)nt;
     int grid = 256;                                    // one workgroup per CU (LDS), each walks ntiles / 256 tiles
     if (grid > k.ntiles) grid = k.ntiles;
-    static bool attr_done[16] = {false};
+    static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 16 || !attr_done[dev]) {
