@@ -187,12 +187,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (args.gpus, args.gpus))
+    # YOLO_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share
+    # devices and the three scalar reductions go through host tensors); the driver's runs use RCCL, one rank per GPU
+    backend = os.environ.get("YOLO_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
 
     from yolo_amd.model import yolov3
     from yolo_amd.shard import shard_bounds
@@ -223,7 +232,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out
@@ -300,7 +309,7 @@ def main():
             dts, outs = timed(shard_pass, reps, 1)
             nd = sum(int(o[4].sum().item()) for o in outs)
             if dist is not None:
-                t = torch.tensor([nd], dtype=torch.int64, device="cuda")
+                t = torch.tensor([nd], dtype=torch.int64, device=red_dev)
                 dist.all_reduce(t)
                 nd = int(t.item())
             side["sharded_512"] = {"global_batch": G, "n_gpus": world, "images_per_sec": round(G * reps / dts, 2),
