@@ -622,6 +622,17 @@ extern "C" int yolo_debug_read_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+// LDS swizzle of the halo kernel: 16-byte chunk c of patch / weight row r lives at chunk c ^ lds_swz<MS>(r) of its 128-byte row.
+// ds_read_b128 is served in four groups of 16 lanes ({0-3,12-15,20-27}, ... : MI355X_MICROARCH.md, LDS), 16 bytes = 4 of the
+// 64 banks per lane, two rows per bank wrap.  32-row fragments (one chunk column per group): (r >> 1) & 7 separates any 16
+// rows.  16-row fragments of v_mfma_f32_16x16x32_bf16 put chunk columns c and c ^ 1 into one group (lanes 0-15 / 16-31):
+// with (r >> 1) & 7 two rows whose terms differ by exactly 1 collide whenever the fragment's first row is not a multiple of
+// 4 - every shifted tap of the patch (SQ_LDS_BANK_CONFLICT was 27 % of the LDS cycles).  An even term, 2 * ((r >> 1) & 3),
+// never maps c and c ^ 1 of two rows onto each other and still separates the four same-parity rows of a column: conflict-free
+// for every first row.
+template <int MS>
+__device__ __forceinline__ int lds_swz(int row) { return MS == 16 ? ((row >> 1) & 3) << 1 : (row >> 1) & 7; }
+
 // ---- 3x3 stride-1 convolution with an LDS-resident input patch ("halo" kernel) -------------------
 // The im2col kernel above re-loads every input pixel once per tap (9x) and is bound by the global->LDS
 // fill rate (measured ~900 cycles per 32 KB stage, the MFMAs of that stage need 512).  Here a tile of BM
@@ -680,7 +691,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
     if (tid < 32) ((unsigned*)zrow)[tid] = 0u;    // ordered before the first fragment read by the loop's barrier
 
     // ---- loader state ----------------------------------------------------------------------------
-    const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const int chunk = (lane & 7) ^ lds_swz<MS>(8 * (wave & 1) + (lane >> 3));   // rows 8 (wave + NW i) + (lane >> 3), NW even
     const int ngroups = prows >> 3;               // 8-row LDS-DMA pieces of the patch
     // Addresses are a wave-uniform 64-bit base (SALU) + a 32-bit per-lane offset, so a piece costs almost
     // no VALU.  Patch rows outside the tensor are only ever referenced by masked taps: they are clamped
@@ -737,7 +748,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
     for (int t = 0; t < TN; ++t) {
         const int row = wn0 + t * MS + fr;
         b_row_off[t] = row * 128;
-        b_sx[t] = (((row >> 1) & 7) ^ fh) << 4;
+        b_sx[t] = (lds_swz<MS>(row) ^ fh) << 4;
     }
 
     AccT acc[TM][TN];
@@ -791,7 +802,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
                 const int prow = wm0 + i * MS + fr + shift;
                 const bool ok = (a_mask[i] >> t) & 1;
                 const char* rowp = ok ? patch + prow * 128 : zrow;     // masked tap: read zeros
-                const int sx = (((prow >> 1) & 7) ^ fh) << 4;
+                const int sx = (lds_swz<MS>(prow) ^ fh) << 4;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) af[kk][i] = *(const u32x4*)(rowp + ((kk << KSH) ^ sx));
             }
