@@ -316,19 +316,26 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvK& p, AccT (&acc)[T
                 if constexpr (!BF16) rres[it][1] = *(const u32x4*)(rp + 16);
             }
         }
+        auto to_lds = [&](auto mode) {              // activation mode as a compile-time constant: no branch per element
+            constexpr int MODE = decltype(mode)::value;
 #pragma unroll
-        for (int ii = 0; ii < IPS; ++ii) {
-            const int i = s * IPS + ii;
+            for (int ii = 0; ii < IPS; ++ii) {
+                const int i = s * IPS + ii;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < MS * MS / 64; ++r) {
-                    const int row = ii * MS + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    float v = acc[i][j][r] + bv[j];
-                    v = leaky == 1 ? leaky_v3(v) : leaky == 2 ? __builtin_fmaxf(0.1f * v, v) : v;
-                    ct[row * LDW + j * MS + fr] = v;
-                }
-        }
+                    for (int r = 0; r < MS * MS / 64; ++r) {
+                        const int row = ii * MS + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        float v = acc[i][j][r] + bv[j];
+                        if constexpr (MODE == 1) v = leaky_v3(v);
+                        else if constexpr (MODE == 2) v = __builtin_fmaxf(0.1f * v, v);
+                        ct[row * LDW + j * MS + fr] = v;
+                    }
+            }
+        };
+        if (leaky == 1) to_lds(std::integral_constant<int, 1>{});
+        else if (leaky == 2) to_lds(std::integral_constant<int, 2>{});
+        else to_lds(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         STAMP(6);
