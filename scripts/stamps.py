@@ -41,6 +41,13 @@ for idx in [int(x) for x in a.only.split(",")]:
             for n_, v in zip(nm, med):
                 print("   %-12s %10.0f cycles  (%5.1f%%)   %.0f / step" % (n_, v, 100 * v / med[7], v / nsteps))
         continue
+    raw0 = buf.reshape(64, 8)[:, 0]
+    raw0 = raw0[buf.reshape(64, 8)[:, 4] > 0]
+    ticks, cyc = (raw0 >> np.uint64(32)).astype(np.float64), (raw0 & np.uint64(0xffffffff)).astype(np.float64)
+    if k == 3 and s == 1 and np.median(ticks) > 0:
+        print("   whole tile: %.0f cycles in %.2f us -> in-kernel clock %.0f MHz (median over sampled workgroups)" % (
+            np.median(cyc), np.median(ticks) / 100.0, np.median(cyc / ticks) * 100.0))
+        st[:, 0] = 0
     med = np.median(st, axis=0)
     tot = med.sum()
     for n_, v in zip(names, med):

@@ -769,6 +769,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
 #ifdef YOLO_CONV_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tbeg_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long rbeg_ = __builtin_amdgcn_s_memrealtime();   // 100 MHz: in-kernel clock = cycles / ticks x 100 MHz
     unsigned long long tl_ = tbeg_;
 #endif
     // ---- prologue: whole patch of chunk 0 + weight tile (0,0) ----------------------------------------
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
 #ifdef YOLO_CONV_STAMPS
     {
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();
-        st_[0] = t_ - tl_;
+        st_[0] = ((__builtin_amdgcn_s_memrealtime() - rbeg_) << 32) | ((t_ - tbeg_) & 0xffffffffull);   // whole tile: 100 MHz ticks | shader cycles
         tl_ = t_;
     }
     if ((blockIdx.x & 63) == 0 && tid == 0 && (blockIdx.x >> 6) < 64) {
