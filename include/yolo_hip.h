@@ -164,7 +164,8 @@ int yolo_net_detect(YoloNet* net, const float* images, int B, int H, int W, cons
  * labels [B,cap], counts [B]: the outputs of yolo_nms / yolo_detect_post / yolo_net_detect (cap = class_num * max_boxes).
  * scale_xy: DEVICE float32 [B,2] = (width_ori / new_w, height_ori / new_h) per image, or NULL (boxes stay in network pixels).
  * rows: DEVICE float32 [B*cap, 7], filled densely in image order with (image_base + image index, x0, y0, x1, y1, score,
- * label); offsets: DEVICE int32 [B+1], rows of image i are [offsets[i], offsets[i+1]); offsets[B] = number of rows. */
+ * label); offsets: DEVICE int32 [B+1], rows of image i are [offsets[i], offsets[i+1]); offsets[B] = number of rows.
+ * boxes must be 16-byte aligned; image_base + B < 2^24 (the index travels as float32). */
 int yolo_pack_detections(const float* boxes, const float* scores, const int32_t* labels, const int32_t* counts, int B,
                          int cap, const float* scale_xy, int image_base, float* rows, int32_t* offsets, void* stream);
 

@@ -640,6 +640,7 @@ extern "C" int yolo_pack_detections(const float* boxes, const float* scores, con
     using namespace yolo;
     YOLO_REQUIRE(boxes && scores && labels && counts && rows && offsets, YOLO_ERR_ARG, "pack_detections: null pointer");
     YOLO_REQUIRE(B > 0 && cap > 0 && B <= (1 << 20) && image_base >= 0, YOLO_ERR_ARG, "pack_detections: bad size");
+    YOLO_REQUIRE(((uintptr_t)boxes & 15) == 0, YOLO_ERR_ARG, "pack_detections: boxes must be 16-byte aligned (one box per load)");
     YOLO_REQUIRE((long long)B * cap < (1ll << 31) / 8 && (long long)image_base + B < (1 << 24), YOLO_ERR_SHAPE,
                  "pack_detections: problem too large (image indices are carried as float32)");
     hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, B, cap, offsets);
