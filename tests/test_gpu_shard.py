@@ -84,6 +84,24 @@ def test_pack_detections_rescale_vs_reference_arithmetic(torch_cuda, oracle):
     np.testing.assert_array_equal(rows2[:m0, 1:5].cpu().numpy(), ob[0, :m0].cpu().numpy())
 
 
+def test_pack_detections_rejects_misaligned_boxes(torch_cuda):
+    """yolo_pack_detections loads one box per 16-byte access: a boxes pointer that is not 16-byte aligned (a view into a
+    larger buffer) is refused with an argument error instead of being read with misaligned vector loads."""
+    import torch
+    from yolo_amd import _lib, _tensor
+    n, cap = 2, 8
+    buf = torch.zeros(n * cap * 4 + 4, device="cuda")
+    boxes = buf[1:]                                                  # 4 bytes past a 16-byte boundary
+    scores = torch.zeros(n, cap, device="cuda")
+    labels = torch.zeros(n, cap, dtype=torch.int32, device="cuda")
+    counts = torch.ones(n, dtype=torch.int32, device="cuda")
+    rows = torch.zeros(n * cap, 7, device="cuda")
+    offsets = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    with pytest.raises((ValueError, RuntimeError), match="16-byte"):
+        _lib.check(_lib.lib().yolo_pack_detections(boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), counts.data_ptr(), n, cap,
+                                                   None, 0, rows.data_ptr(), offsets.data_ptr(), _tensor.stream_ptr()))
+
+
 def _iou(a, b):
     iw = np.maximum(0.0, np.minimum(a[2], b[:, 2]) - np.maximum(a[0], b[:, 0]))
     ih = np.maximum(0.0, np.minimum(a[3], b[:, 3]) - np.maximum(a[1], b[:, 1]))
