@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=16, help="batch-1 images of the CPU baseline sample (+ the same number at batch 8)")
     ap.add_argument("--layer-table", default="", help="write the per-layer timing table to this file")
     ap.add_argument("--lanes", type=int, default=0, help="sub-batches run concurrently on separate streams inside the library "
-                                                         "(YOLO_LANES); 0 = library default (2 from batch 12 up, 3 from batch 48 up)")
+                                                         "(YOLO_LANES); 0 = library default (2 from 16 images of 416 x 416 up, 3 from 56 up)")
     ap.add_argument("--h2d", action="store_true", help="also report the rate with the batch copied from pinned host memory "
                                                        "inside every step (extra key, never `value`)")
     args = ap.parse_args()
@@ -240,7 +240,8 @@ def main():
     # forward -> predict -> conf*prob -> per-class NMS (gpu_nms defaults), the last three fused, as one library call
     dt, out = timed(lambda: net.detect(images, 50, 0.5, 0.5), args.steps, args.warmup)
     ndet = int(out[4].sum().item())
-    lanes = int(os.environ.get("YOLO_LANES", "0")) or (3 if B >= 48 else 2 if B >= 12 else 1)
+    work = B * S * S // (416 * 416)                        # the library's default (net.hip lane_count)
+    lanes = int(os.environ.get("YOLO_LANES", "0")) or (3 if work >= 56 else 2 if work >= 16 else 1)
 
     roofline, layer_ms, info, flops, kernels = dominant_kernel(net, images, args.dtype, B, S, lanes)
     if args.layer_table and rank == 0:

@@ -505,13 +505,15 @@ extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->
 // GPU: the partly filled last round of workgroups of one launch (e.g. 676 tiles on 512 slots) and the drain / fill
 // between dependent launches are covered by the other lane's kernels.  Results do not depend on the split: every
 // output element is accumulated in the same order whatever tile or batch it is part of.
-// Default: 2 lanes from batch 12 up, 3 from batch 48 up.  YOLO_LANES=<n> in the environment (read per call) sets the number of lanes;
-// 1 = one launch per layer for the whole batch.
+// Default, by the work of the call in 416 x 416 images (B * H * W / 416^2): 2 lanes from 16 up, 3 from 56 up (round-2 kernels,
+// one MI355X: batch 12 one lane 2.02 ms vs two 2.13; batch 16 2.19 / 2.15; batch 32 3.11 / 2.87; batch 48 3.85 / 3.73 / 3.82
+// for 1 / 2 / 3 lanes; batch 64 5.18 / 4.91 / 4.88; 608 x 608 batch 16 3.49 / 3.36 / 3.35).
+// YOLO_LANES=<n> in the environment (read per call) sets the number of lanes; 1 = one launch per layer for the whole batch.
 constexpr int MAX_LANES = 8;
-static int lane_count(int B) {
+static int lane_count(int B, int H, int W) {
     const char* e = getenv("YOLO_LANES");
-    int n = e ? atoi(e) : (B >= 48 ? 3 : B >= 12 ? 2 : 1);   // measured (scripts/lanes.py): +5..8 % from batch 12 up, a loss below 8;
-                                                             // a third lane adds 0.2..1 % at batch 64
+    const long long work = (long long)B * H * W / (416 * 416);
+    int n = e ? atoi(e) : (work >= 56 ? 3 : work >= 16 ? 2 : 1);
     if (n < 1) n = 1;
     if (n > MAX_LANES) n = MAX_LANES;
     return n < B ? n : B;
@@ -669,7 +671,7 @@ static int run_lanes(YoloNet* net, int lanes, int B, hipStream_t main_s, F&& lan
 static int forward_lanes(YoloNet* net, const float* images, int B, int H, int W, void* workspace, size_t workspace_bytes,
                          float* fm1, float* fm2, float* fm3, void* stream) {
     YOLO_REQUIRE(net && B > 0, YOLO_ERR_ARG, "forward: bad handle or batch");
-    const int lanes = lane_count(B);
+    const int lanes = lane_count(B, H, W);
     if (lanes == 1) return forward_impl(net, images, B, H, W, workspace, workspace_bytes, fm1, fm2, fm3, stream, nullptr);
     YOLO_REQUIRE(images && workspace && fm1 && (net->kind == 2 || (fm2 && fm3)), YOLO_ERR_ARG, "forward: null pointer");
     YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "forward: workspace must be 256-byte aligned");
@@ -736,7 +738,7 @@ extern "C" int yolo_net_detect(YoloNet* net, const float* images, int B, int H, 
     YOLO_REQUIRE(B > 0 && max_boxes > 0, YOLO_ERR_ARG, "yolo_net_detect: non-positive size");
     YOLO_REQUIRE(H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, YOLO_ERR_SHAPE, "yolo_net_detect: H, W must be multiples of 32 (got %dx%d)", H, W);
     YOLO_REQUIRE(((uintptr_t)workspace & 255) == 0, YOLO_ERR_ARG, "yolo_net_detect: workspace must be 256-byte aligned");
-    const int lanes = lane_count(B);
+    const int lanes = lane_count(B, H, W);
     DetectLayout lay[MAX_LANES];
     size_t base[MAX_LANES + 1] = {0};
     for (int i = 0; i < lanes; ++i) {
