@@ -235,21 +235,19 @@ __global__ __launch_bounds__(256) void decode_sparse_kernel(DecodeK k, float thr
 // into the first non-empty bin while that bin alone holds more than kSortCap keys (equal scores differ only in the
 // index bits); keys are unique, so the last level always separates them.
 template <int MODE>
-__global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict__ boxes, int n, int C, int max_boxes,
-                                                         float iou_thr, const int* __restrict__ cand_count,
-                                                         u64* __restrict__ cand_keys, int* __restrict__ sel_count,
-                                                         int* __restrict__ sel_idx, float* __restrict__ sel_score) {
+__device__ __forceinline__ void nms_select_block(const int bc, const float* __restrict__ boxes, int n, int C, int max_boxes,
+                                                 float iou_thr, const int* __restrict__ cand_count,
+                                                 u64* __restrict__ cand_keys, int* __restrict__ sel_count,
+                                                 int* __restrict__ sel_idx, float* __restrict__ sel_score, f32x4* selbox) {
     __shared__ u64 skeys[kSortCap];            // 16 KB: the round's keys; before they are gathered, the radix histogram
-    extern __shared__ f32x4 selbox[];          // [max_boxes] selected boxes (dynamic: a small LDS footprint keeps 8
-                                               // workgroups per CU for the usual few candidates per class)
     __shared__ u64 masks[64];
     __shared__ int part[256];
     int* const hist = (int*)skeys;             // 4096 bins = the same 16 KB; never live together with the keys
     static_assert(sizeof(u64) * kSortCap >= sizeof(int) * 4096, "histogram must fit the key buffer");
     __shared__ int s_take, s_first, s_cnt, s_nsel;
 
-    const int bc = blockIdx.x;                 // b * C + c
-    const int b = bc / C;
+    __syncthreads();                           // the shared arrays are free again (previous class of this workgroup)
+    const int b = bc / C;                      // bc = b * C + c
     const int k = cand_count[bc];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* out_idx = sel_idx + (long long)bc * max_boxes;
@@ -397,6 +395,80 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
     if (tid == 0) sel_count[bc] = nsel;
 }
 
+// The kernel: a workgroup takes four (image, class) lists.  With a detector's threshold nearly all of them hold a handful of
+// candidates, so each WAVE settles one list of <= 64 candidates by itself - keys ranked by 64 wave shuffles (keys are
+// unique), placed through a 64-entry LDS row, then the same single-chunk greedy step as above (IoU bit masks by shuffles,
+// wave-uniform suppression scan): no workgroup barrier, and four lists per workgroup instead of one with three idle waves.
+// Lists with more than 64 candidates go through nms_select_block, one workgroup per list (the second part of the grid: a
+// workgroup per list that exits at once when its list is short - the stress configuration keeps its 640 parallel workgroups).
+// Same keys, same order, same comparisons: the selected indices are the ones the block path gives.
+template <int MODE>
+__global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict__ boxes, int n, int C, int nbc, int max_boxes,
+                                                         float iou_thr, const int* __restrict__ cand_count,
+                                                         u64* __restrict__ cand_keys, int* __restrict__ sel_count,
+                                                         int* __restrict__ sel_idx, float* __restrict__ sel_score) {
+    extern __shared__ f32x4 selbox[];          // [max_boxes] selected boxes of the block path (dynamic: a small LDS footprint
+                                               // keeps 8 workgroups per CU)
+    __shared__ u64 wsort[4][64];
+    __shared__ u64 wmask[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nsmall = (nbc + 3) >> 2;              // workgroups [0, nsmall): four short lists each; [nsmall, nsmall + nbc): one
+    if ((int)blockIdx.x >= nsmall) {                // workgroup per list, which leaves at once unless the list is a long one
+        const int bc = (int)blockIdx.x - nsmall;
+        if (cand_count[bc] > 64)
+            nms_select_block<MODE>(bc, boxes, n, C, max_boxes, iou_thr, cand_count, cand_keys, sel_count, sel_idx, sel_score, selbox);
+        return;
+    }
+    const int bc0 = blockIdx.x * 4;
+    {
+        const int bc = bc0 + wave;
+        const int k = bc < nbc ? cand_count[bc] : -1;
+        if (k == 0) {
+            if (lane == 0) sel_count[bc] = 0;
+        } else if (k > 0 && k <= 64) {
+            const int b = bc / C;
+            const f32x4* bx = (const f32x4*)boxes + (long long)b * n;
+            const u64 key = lane < k ? cand_keys[(long long)bc * n + lane] : kDead;
+            int rank = 0;
+            for (int j = 0; j < k; ++j) {
+                const u64 kj = ((u64)(unsigned)__shfl((int)(key >> 32), j) << 32) | (unsigned)__shfl((int)key, j);
+                rank += kj < key;
+            }
+            if (lane < k) wsort[wave][rank] = key;
+            __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): the row is written and read by this wave only
+            __builtin_amdgcn_wave_barrier();
+            const bool valid = lane < k;
+            const u64 mykey = valid ? wsort[wave][lane] : 0ull;
+            const unsigned idx = valid ? key_index<MODE>(mykey) : 0u;
+            f32x4 box = {0.f, 0.f, 0.f, 0.f};
+            if (valid) box = bx[idx];
+            u64 mask = 0;                           // bit j: the better-ranked candidate j suppresses me
+            for (int j = 0; j + 1 < k; ++j) {
+                f32x4 o;
+                o[0] = __shfl(box[0], j); o[1] = __shfl(box[1], j); o[2] = __shfl(box[2], j); o[3] = __shfl(box[3], j);
+                if (j < lane && suppresses<MODE>(o, box, iou_thr)) mask |= 1ull << j;
+            }
+            wmask[wave][lane] = mask;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            u64 selected = 0;
+            int cntsel = 0;
+            for (int t = 0; t < k; ++t) {           // suppression scan (wave-uniform)
+                if (cntsel < max_boxes && (wmask[wave][t] & selected) == 0) {
+                    selected |= 1ull << t;
+                    ++cntsel;
+                }
+            }
+            if ((selected >> lane) & 1) {
+                const int pos = __popcll(selected & ((1ull << lane) - 1));
+                sel_idx[(long long)bc * max_boxes + pos] = (int)idx;
+                if (sel_score) sel_score[(long long)bc * max_boxes + pos] = key_score(mykey);
+            }
+            if (lane == 0) sel_count[bc] = cntsel;
+        }
+    }
+}
+
 // ---- 3. class-ordered dense output ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                          int n, int C, int max_boxes, const int* __restrict__ sel_count,
@@ -463,7 +535,7 @@ static int nms_run(const float* boxes, const float* scores, int B, int n, int C,
     const unsigned ctiles = (unsigned)((C + kTileC - 1) / kTileC);
     hipLaunchKernelGGL(nms_compact_kernel<MODE>, dim3(tiles, B, ctiles), dim3(256), 0, stream, scores, n, C, st, w.cand_count, w.cand_keys);
     YOLO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(nms_select_kernel<MODE>, dim3((unsigned)(B * C)), dim3(256), (size_t)max_boxes * 16, stream, boxes, n, C, max_boxes, it,
+    hipLaunchKernelGGL(nms_select_kernel<MODE>, dim3((unsigned)((B * C + 3) / 4 + B * C)), dim3(256), (size_t)max_boxes * 16, stream, boxes, n, C, B * C, max_boxes, it,
                        w.cand_count, w.cand_keys, w.sel_count, w.sel_idx, (float*)nullptr);
     YOLO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, stream, boxes, scores, n, C, max_boxes,
@@ -494,7 +566,7 @@ static int post_run(DecodeK k, int B, int max_boxes, float st, float it, float* 
     else
         hipLaunchKernelGGL(fn, dim3(tiles, B), dim3(256), lds, stream, k, st, w.cand_count, w.cand_keys);
     YOLO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(nms_select_kernel<YOLO_NMS_TF>, dim3((unsigned)(B * C)), dim3(256), (size_t)max_boxes * 16, stream, w.boxes, n, C, max_boxes, it,
+    hipLaunchKernelGGL(nms_select_kernel<YOLO_NMS_TF>, dim3((unsigned)((B * C + 3) / 4 + B * C)), dim3(256), (size_t)max_boxes * 16, stream, w.boxes, n, C, B * C, max_boxes, it,
                        w.cand_count, w.cand_keys, w.sel_count, w.sel_idx, w.sel_score);
     YOLO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, stream, w.boxes, (const float*)nullptr, n, C,
