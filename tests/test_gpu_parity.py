@@ -567,6 +567,36 @@ def test_alternative_conv_tilings_vs_oracle(net_bf16, oracle, oracle_params, cfg
 
 
 @pytest.mark.parametrize("mode", ["tf", "py"])
+def test_nms_short_and_long_lists_side_by_side(torch_cuda, oracle, mode):
+    """the selection kernel settles lists of <= 64 candidates with one wave each (four lists per workgroup) and longer ones
+    with a workgroup each: classes with 0, 1, 63, 64, 65 and 300 candidates in ONE call, clustered boxes (long suppression
+    chains) and tied scores, give the oracle's keep-indices on both sides of the boundary."""
+    from yolo_amd.utils import nms_utils
+    rng = np.random.default_rng(64)
+    n, counts = 400, (0, 1, 63, 64, 65, 300, 64, 2)
+    C = len(counts)
+    boxes = _boxes(rng, n, clustered=12, jitter=4.0)
+    scores = np.zeros((n, C), np.float32)
+    for c, k in enumerate(counts):
+        pick = rng.permutation(n)[:k]
+        scores[pick, c] = (0.5 + 0.5 * rng.integers(0, 8, k) / 8).astype(np.float32)      # eight distinct values: many ties
+    if mode == "tf":
+        ob, osc, ol, oi, oc = nms_utils.gpu_nms_batched(np.stack([boxes, boxes[::-1]]), np.stack([scores, scores[::-1]]), C, 20, 0.4, 0.45)
+        for b, (bx, sc) in enumerate(((boxes, scores), (boxes[::-1], scores[::-1]))):
+            m = int(oc[b])
+            _, _, rl, ri = oracle.gpu_nms(np.ascontiguousarray(bx), np.ascontiguousarray(sc), C, 20, 0.4, 0.45, return_indices=True)
+            assert m == len(ri) and m > 0
+            assert np.array_equal(oi[b, :m].cpu().numpy(), ri) and np.array_equal(ol[b, :m].cpu().numpy(), rl)
+    else:
+        for c, k in enumerate(counts):
+            if k == 0:
+                continue
+            sel = np.nonzero(scores[:, c] > 0)[0]
+            got = nms_utils.py_nms(boxes[sel], scores[sel, c], max_boxes=20, iou_thresh=0.45)
+            assert got == [int(v) for v in oracle.py_nms(boxes[sel], scores[sel, c], 20, 0.45)], (c, k)
+
+
+@pytest.mark.parametrize("mode", ["tf", "py"])
 def test_nms_many_candidates_with_equal_scores(torch_cuda, oracle, mode):
     """more than 2048 candidates per class whose scores collide: the key ranges of the selection rounds are then cut
     inside the index bits of the keys (deep radix levels), and several rounds are needed when the best boxes
