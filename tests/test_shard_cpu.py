@@ -202,6 +202,37 @@ def test_cfg_parser_vs_reference_block_list():
         cfg.plan_from_blocks(bad)
     with pytest.raises(ValueError):
         cfg.parse_cfg("[net]\nwidth 416\n")
+    with pytest.raises(ValueError):
+        cfg.parse_cfg("width=416\n[net]\n")
+    # the whole block sequence is compared, not only the conv geometry (blocks[i + 1] is block i of the cfg):
+    assert blocks[87]["layers"].replace(" ", "") == "-1,61" and blocks[99]["layers"].replace(" ", "") == "-1,36"
+    ok = copy.deepcopy(blocks)
+    ok[87]["layers"] = "85, 61"                                   # the same sources written as absolute indices
+    ok[84]["layers"] = "79"
+    assert cfg.plan_from_blocks(ok)["class_num"] == 80
+    bad = copy.deepcopy(blocks)
+    bad[87]["layers"] = "-1, 58"                                   # another 512-channel block: the filter sum still fits
+    with pytest.raises(ValueError, match="block 86"):
+        cfg.plan_from_blocks(bad)
+    bad = copy.deepcopy(blocks)
+    bad[99]["layers"] = "-1, 61"                                   # wrong scale: 128 + 512 channels, caught at the route itself
+    with pytest.raises(ValueError, match="block 98"):
+        cfg.plan_from_blocks(bad)
+    bad = copy.deepcopy(blocks)
+    assert bad[5]["type"] == "shortcut"
+    del bad[5]                                                     # a residual add removed: every conv keeps its geometry
+    with pytest.raises(ValueError, match="block 4"):
+        cfg.plan_from_blocks(bad)
+    bad = copy.deepcopy(blocks)
+    assert bad[85]["type"] == "convolutional" and bad[86]["type"] == "upsample"
+    bad[85], bad[86] = bad[86], bad[85]                            # upsample moved in front of the inter conv: filters still chain
+    with pytest.raises(ValueError, match="block 84"):
+        cfg.plan_from_blocks(bad)
+    bad = copy.deepcopy(blocks)
+    bad[83]["mask"] = "3,4,5"
+    with pytest.raises(ValueError, match="block 82"):
+        cfg.plan_from_blocks(bad)
+    assert cfg.expected_layout(80)[36] == ("shortcut", 33) and cfg.expected_layout(80)[86] == ("route", [85, 61])
 
 
 def test_yolov2_darknet_stream_to_variables():

@@ -38,11 +38,8 @@ def parse_anchors(anchor_path):
 
 def read_class_names(class_name_path):
     """misc_utils.py:15-21: one name per line -> {id: name}."""
-    names = {}
-    with open(class_name_path, "r") as data:
-        for ID, name in enumerate(data):
-            names[ID] = name.strip("\n")
-    return names
+    with open(class_name_path, "r") as f:
+        return {idx: line.strip("\n") for idx, line in enumerate(f)}
 
 
 def read_darknet_weights(weights_file):

@@ -49,7 +49,7 @@ def split_variables(stream, num_class=len(cfg.CLASSES), box_per_cell=cfg.BOX_PRE
 def darknet_stream_to_variables(stream, num_class=len(cfg.CLASSES), box_per_cell=cfg.BOX_PRE_CELL):
     """Float32 body of a Darknet yolov2 `.weights` file (after the header; e.g. yolov2-voc.weights) -> the TF variable stream
     `load_variables` / yolo2_net_create take.  Darknet stores, per conv in cfg order (= the call order of build_networks:
-    the 22 trunk convs, the passthrough 1x1 conv, the two head convs), [biases, scales, rolling_mean, rolling_variance]
+    the 20 trunk convs, the passthrough 1x1 conv, the two head convs: 23 in all), [biases, scales, rolling_mean, rolling_variance]
     (batch-norm convs) or [biases], then the kernel as [Cout, Cin, kh, kw] - the layout of yolo_v3/utils/misc_utils.py:45-96
     and yolo-v3/002/darknet.py:212-265.  The reference's conv_layer (yolo_v2.py:75-86) has BOTH a BN shift and an extra
     `biases` variable; Darknet has one: it becomes `shift`, `biases` is zero.  (The reference's reorg channel order,
