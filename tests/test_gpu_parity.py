@@ -547,7 +547,7 @@ def test_load_state_equals_load_weight_stream(net_f32, weight_stream, tmp_path):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("cfg", ["40", "41", "34", "38", "26", "5", "50", "51", "52", "60", "61", "64", "67", "80", "81", "82", "83", "84", "85", "86", "70", "71", "75", "88"])
+@pytest.mark.parametrize("cfg", ["40", "41", "34", "38", "26", "5", "50", "51", "52", "60", "61", "64", "67", "80", "81", "82", "83", "84", "85", "86", "70", "71", "75", "88", "90", "91", "92", "93"])
 def test_alternative_conv_tilings_vs_oracle(net_bf16, oracle, oracle_params, cfg):
     """the selectable tile configurations (YOLO_CONV_CFG: 40 / 41 = 256- / 192-row ping-pong tiles on 16x16x32 MFMAs,
     34 / 38 = the shipped tiling on 16x16x32 MFMAs, 26 = 16-wave tile, 5 = im2col) meet the bf16 tolerance of

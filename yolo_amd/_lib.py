@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libyolo_hip.so")
+# YOLO_HIP_LIB=<path>: measurement scripts load a diagnostic build (make STAMPS=1 / EXP=<n>) instead of the shipped library
+LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "lib", "libyolo_hip.so")
 
 YOLO_DTYPE_F32, YOLO_DTYPE_BF16 = 0, 1
 YOLO_NMS_TF, YOLO_NMS_PY = 0, 1

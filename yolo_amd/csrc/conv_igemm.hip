@@ -33,6 +33,7 @@ __device__ __attribute__((aligned(256))) static const unsigned char g_zero_page[
 // Diagnostic build only (make STAMPS=1): per-phase s_memtime sums of wave 0 of every 64th block.
 // Never compiled into the shipped library; stamp values go to a buffer nothing else reads.
 __device__ unsigned long long g_stamps[64 * 8];
+__device__ unsigned g_census[4096 * 4];      // per workgroup of the halo kernel: HW_ID, XCC_ID, start / end in 100 MHz ticks
 #define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[i] += t_ - tl_; tl_ = t_; } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -467,14 +468,21 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
         const long long toff = (long long)(ky * p.W + kx) * pix_b + cib + in_cb;
         const unsigned tbit = (tap < ntaps) ? (1u << tap) : 0u;
+#if !defined(YOLO_EXP) || YOLO_EXP != 4         // EXP 4: im2col kernel without activation loads in the loop (first stage only)
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const char* src = (a_mask[i] & tbit) ? (p.in + a_off[i] + toff) : (const char*)g_zero_page;
             GLDS16(src, la + i * (NW * 1024));
         }
+#else
+        if (buf == 0 && tap == 0 && cib == chunk * 16)
+            for (int i = 0; i < AI; ++i) GLDS16((a_mask[i] & tbit) ? (p.in + a_off[i] + toff) : (const char*)g_zero_page, la + i * (NW * 1024));
+#endif
         char* lb = lds + buf * BUF_BYTES + A_BYTES + wave * 1024;
+#if !defined(YOLO_EXP) || YOLO_EXP != 5         // EXP 5: ... without weight loads
 #pragma unroll
         for (int i = 0; i < BI; ++i) GLDS16(wsrc + i * w_step, lb + i * (NW * 1024));
+#endif
         // advance to the next K-step
         wsrc += 128;
         cib += 128;
@@ -589,6 +597,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
         STAMP(4);                      // fragment reads + MFMA issue
 #endif
     }
+#if defined(YOLO_EXP) && YOLO_EXP == 6          // EXP 6: im2col kernel without epilogue
+    {
+        float sacc = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < MS * MS / 64; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) ((float*)p.out)[tid] = sacc;
+    }
+#else
     if constexpr (EPASS == 3) {
         static_assert(EPASS != 3 || (MS == 16 && BF16), "register epilogue: bf16 on 16x16x32 MFMAs");
         if constexpr (MS == 16) conv_epilogue_regs<TM, TN>(p, acc, m0, n0, wm0, wn0, lane);
@@ -606,6 +621,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
     conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
 #endif
     }
+#endif
 #ifdef YOLO_CONV_STAMPS
     {
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();
@@ -625,6 +641,13 @@ extern "C" int yolo_debug_read_stamps(unsigned long long* host, int n) {
     if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_stamps)) != hipSuccess) return YOLO_ERR_HIP;
     if (hipDeviceSynchronize() != hipSuccess) return YOLO_ERR_HIP;
     if (hipMemcpy(host, dptr, sizeof(unsigned long long) * (size_t)(n < 512 ? n : 512), hipMemcpyDeviceToHost) != hipSuccess) return YOLO_ERR_HIP;
+    return YOLO_OK;
+}
+extern "C" int yolo_debug_read_census(unsigned* host, int n) {
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_census)) != hipSuccess) return YOLO_ERR_HIP;
+    if (hipDeviceSynchronize() != hipSuccess) return YOLO_ERR_HIP;
+    if (hipMemcpy(host, dptr, sizeof(unsigned) * (size_t)(n < 16384 ? n : 16384), hipMemcpyDeviceToHost) != hipSuccess) return YOLO_ERR_HIP;
     return YOLO_OK;
 }
 #endif
@@ -785,7 +808,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
         const char* patch = patch0 + (SPB ? 0 : (c & 1) * patch_bytes);
         if (SPB && c > 0) {                    // every wave is done with chunk c-1: refill the single patch buffer
             __builtin_amdgcn_s_barrier();
+#if !defined(YOLO_EXP) || YOLO_EXP != 1         // EXP 1: no refill (stale patch): what the exposed refills cost
             for (int sl = 0; sl < slots; ++sl) load_patch_piece(c, sl);
+#endif
         }
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
@@ -795,8 +820,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
             __builtin_amdgcn_sched_barrier(0);
             STAMP(2);
             // prefetch
+#if !defined(YOLO_EXP) || YOLO_EXP != 2         // EXP 2: no weight loads in the loop (stale weights)
             if (t < 8) load_b(c, t + 1, bcur ^ 1);
             else if (c + 1 < nchunks) load_b(c + 1, 0, bcur ^ 1);
+#endif
             if (!SPB && c + 1 < nchunks)
                 for (int sl = t; sl < slots; sl += 9) load_patch_piece(c + 1, sl);
             STAMP(3);
@@ -850,6 +877,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
 #endif
         }
     }
+#if defined(YOLO_EXP) && YOLO_EXP == 3          // EXP 3: no epilogue (accumulators kept live, one store per lane)
+    {
+        float sacc = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < MS * MS / 64; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) ((float*)p.out)[tid] = sacc;
+    }
+#else
     if constexpr (EPASS == 3) {
         static_assert(EPASS != 3 || (MS == 16 && BF16), "register epilogue: bf16 on 16x16x32 MFMAs");
         if constexpr (MS == 16) conv_epilogue_regs<TM, TN>(p, acc, m0, n0, wm0, wn0, lane);
@@ -867,6 +901,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
     conv_epilogue<BF16, BM, BN, TM, TN, NT, MS, AccT, EPASS>(p, acc, lds, m0, n0, wm0, wn0, tid, fr, fh);
 #endif
     }
+#endif
 #ifdef YOLO_CONV_STAMPS
     {
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();
@@ -876,6 +911,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
     if ((blockIdx.x & 63) == 0 && tid == 0 && (blockIdx.x >> 6) < 64) {
         unsigned long long* o = g_stamps + (blockIdx.x >> 6) * 8;
         for (int i = 0; i < 8; ++i) o[i] = st_[i];
+    }
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_census[blockIdx.x * 4 + 0] = hw;
+        g_census[blockIdx.x * 4 + 1] = xcc;
+        g_census[blockIdx.x * 4 + 2] = (unsigned)rbeg_;
+        g_census[blockIdx.x * 4 + 3] = (unsigned)__builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
@@ -1194,6 +1238,182 @@ static int launch_p8(const ConvK& k, hipStream_t stream) {
     return YOLO_OK;
 }
 
+// ---- 1x1 stride-1 convolution with the activations loaded straight into MFMA operand registers ("direct-A", bf16) ----
+// The im2col kernel stages A and B through LDS by LDS-DMA; on the 1x1 layers (4 - 16 K-steps per tile) it is bound by the
+// issue cost and the landing latency of those pieces, not by HBM or the matrix pipe (round 3: dropping either operand's
+// pieces from the loop made the 1x1 layers 1.3 - 1.5x faster).  A 1x1 conv needs no im2col: a pixel's K-chunk is 128
+// contiguous bytes of its row, and a wave that owns whole pixels x ALL BN output channels is the only reader of its rows.
+//   * each wave owns 32 pixels x BN channels (2 x TN tiles of v_mfma_f32_16x16x32_bf16, operands swapped: D[channel][pixel],
+//     so the register epilogue applies); lane (pixel fr, quarter fq) loads 32 contiguous bytes of its pixel's 128-byte
+//     K-chunk with two global_load_dwordx4 - the four lanes of a pixel cover one whole cache line.  MFMA kk of the step
+//     takes the lane's kk-th 16 bytes, i.e. the k-chunk 2 fq + kk (any k permutation is fine as long as B agrees).
+//   * only the [BN x 128 B] weight tile goes through LDS (LDS-DMA, double-buffered, shared by the workgroup's waves).  Its
+//     rows are stored with the k-chunks permuted (logical chunk 2 q + k at slot 4 k + q) so that the fragment reads use the
+//     addressing - and the conflict-free XOR swizzle - of the im2col kernel.
+//   * activation loads run two K-steps ahead in two register sets; they are inline asm so that hipcc neither counts nor
+//     drains them (cdna_hip_programming.md 5.7 form (ii)): the wait before a set's first use names its registers.
+//     vmcnt order per step: [weights s+1 (BI pieces)] ... [activations s+2 (4 loads)], so vmcnt(4) at the top of step s+1
+//     leaves exactly the youngest activation set in flight.
+#define GLOAD16(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr))
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+// D: K-steps the loads run ahead (D activation register sets, D + 1 weight buffers); NW waves of 32 pixels x BN = 16 TN channels.
+// PERM: a lane's two loads are the adjacent 16-byte pieces 2 fq, 2 fq + 1 of the K-chunk (described above); !PERM: pieces fq and
+// 4 + fq (the plain fragment order: every load instruction reads 64 contiguous bytes per pixel).
+template <int NW, int TN, int D, int MINW, bool PERM = true>
+__global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) {
+    constexpr int TM = 2;
+    constexpr int BM = NW * 32, BN = TN * 16;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int BI = BN / 8 / NW;
+    constexpr int V = BI + 2 * TM;                    // vector-memory operations a wave issues per K-step
+    static_assert(BN % (8 * NW) == 0 && NW % 2 == 0 && BI >= 1, "weight loader geometry");
+    static_assert(D >= 2 && D <= 4 && V * (D - 1) < 64, "prefetch depth");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = tile / p.ntn;
+    const int nt = tile - mt * p.ntn;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = p.nsteps;
+
+    // ---- weight loader: this lane fills slot (lane & 7) of row 8 g + (lane >> 3), g = wave + NW i
+    const int phys = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);      // slot ^ swizzle(row) = 4 k + q of the stored chunk
+    const int chunk = PERM ? 2 * (phys & 3) + (phys >> 2) : phys;             // ... which is logical k-chunk 2 q + k
+    const char* wsrc = p.w + (long long)(n0 + 8 * wave + (lane >> 3)) * p.kpad_bytes + chunk * 16;
+    const long long w_step = (long long)(8 * NW) * p.kpad_bytes;
+    auto load_b = [&](int buf) {
+        char* lb = lds + buf * B_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) GLDS16(wsrc + i * w_step, lb + i * (NW * 1024));
+        wsrc += 128;
+    };
+    // ---- activation rows of this lane (rows past M are clamped; the epilogue drops them)
+    const char* aptr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m0 + wave * 32 + i * 16 + fr;
+        m = m < p.M ? m : p.M - 1;
+        aptr[i] = p.in + ((long long)m * p.in_ld + p.in_coff) * 2 + fq * (PERM ? 32 : 16);
+    }
+    int b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = j * 16 + fr;
+        b_off[j] = row * 128;
+        b_sw[j] = (((row >> 1) & 7) ^ fq) << 4;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 a[D][TM][2];                                // register set d: K-steps s with s % D == d
+    auto load_a = [&](u32x4 (&x)[TM][2]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            GLOAD16(x[i][0], aptr[i], 0);
+            if constexpr (PERM) GLOAD16(x[i][1], aptr[i], 16);
+            else GLOAD16(x[i][1], aptr[i], 64);
+            aptr[i] += 128;
+        }
+    };
+    auto compute = [&](const char* base, u32x4 (&x)[TM][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 bf[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(base + b_off[j] + ((kk << 6) ^ b_sw[j]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, x[i][kk]), acc[i][j], 0, 0, 0);
+        }
+    };
+    // One K-step.  Issue order of a wave's vector-memory operations is [weights u][activations u] for u = 0, 1, 2, ...; at the
+    // top of step s everything up to u = s must have landed, the (at most D - 1) younger groups may stay in flight.  This
+    // wave's share: counted vmcnt; the other waves' weight pieces: the barrier.  Then the weights of s + D go into the buffer
+    // last read in step s - 1, step s is computed, and the register set just consumed is refilled for step s + D.
+    int bcur = 0;
+    auto step = [&](int s, u32x4 (&x)[TM][2]) {
+        const int younger = nsteps - 1 - s;           // groups issued after step s's
+        if (younger >= D - 1) wait_vmcnt<V * (D - 1)>();
+        else if (D > 3 && younger == 2) wait_vmcnt<V * 2>();
+        else if (D > 2 && younger == 1) wait_vmcnt<V>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]));   // no consumer of the set is scheduled above this point
+#if !defined(YOLO_EXP) || YOLO_EXP != 8         // EXP 8: direct kernel without weight loads in the loop
+        if (s + D < nsteps) load_b(bcur == 0 ? D : bcur - 1);
+#endif
+        compute(lds + bcur * B_BYTES, x);
+        __builtin_amdgcn_sched_barrier(0);
+#if !defined(YOLO_EXP) || YOLO_EXP != 7         // EXP 7: ... without activation loads in the loop
+        if (s + D < nsteps) load_a(x);
+#endif
+        bcur = bcur == D ? 0 : bcur + 1;
+    };
+    static_assert(TM == 2, "the fence names the four registers of a set");
+
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nsteps) { load_b(d); load_a(a[d]); }
+    for (int s = 0; s < nsteps; s += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (s + d < nsteps) step(s + d, a[d]);
+    }
+#if defined(YOLO_EXP) && YOLO_EXP == 9          // EXP 9: ... without epilogue
+    {
+        float sacc = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 4; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) ((float*)p.out)[tid] = sacc;
+    }
+#else
+    conv_epilogue_regs<TM, TN>(p, acc, m0, n0, wave * 32, 0, lane);
+#endif
+}
+#undef GLOAD16
+
+template <int NW, int TN, int D, int MINW, bool PERM = true>
+static int launch_direct1x1(const ConvK& k, hipStream_t stream) {
+    constexpr int BM = NW * 32, BN = TN * 16;
+    constexpr int lds_bytes = (D + 1) * BN * 128;
+    YOLO_REQUIRE(k.ksize == 1 && k.stride == 1 && (k.Cin * 2) % 128 == 0 && !k.upsample && !k.reorg && !k.out_f32, YOLO_ERR_UNSUPPORTED,
+                 "conv1x1 direct: plain bf16 1x1 stride-1 layers with Cin a multiple of 64 only");
+    auto fn = conv1x1_direct_kernel<NW, TN, D, MINW, PERM>;
+    static std::atomic<bool> attr_done[16];
+    int dev = 0;
+    YOLO_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_done[dev]) {
+        YOLO_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        if (dev < 16) attr_done[dev] = true;
+    }
+    ConvK kk = k;
+    kk.ntm = (k.M + BM - 1) / BM;
+    kk.ntn = (k.Cout + BN - 1) / BN;
+    note_kernel("yolo::conv1x1_direct_kernel<%d, %d, %d, %d, %s>", NW, TN, D, MINW, PERM ? "true" : "false");
+    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * NW), lds_bytes, stream, kk);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
 template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32, int EPASS = 1, int MINW = 1>
 static int launch_halo(const ConvK& k, hipStream_t stream) {
     if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32, EPASS == 3 ? 0 : EPASS, MINW>(k, stream);
@@ -1292,6 +1512,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
             }
     }
     if (cfg >= 80 && cfg < 90 && (halo_ok || k.Cout <= 64)) cfg = -1;
+    if (cfg >= 90 && cfg < 100 && !(k.ksize == 1 && k.stride == 1 && !k.upsample && !k.reorg && !k.out_f32 && BF16 && (k.Cin * 2) % 128 == 0)) cfg = -1;
     if (cfg >= 20 && cfg < 80 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
@@ -1302,7 +1523,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         const int prows256 = 256 + 2 * k.W + 2 + 7;
         const int patch_bufs = k.Cin * sz > 128 ? 2 : 1;
         if (k.Cout <= 32) cfg = 10;
-        else if (k.Cout <= 64) cfg = k.ksize == 1 ? 14 : 12;
+        else if (k.Cout <= 64) cfg = (BF16 && k.ksize == 1 && k.stride == 1 && !k.upsample && !k.reorg && !k.out_f32 && (k.Cin * 2) % 128 == 0) ? 97 : k.ksize == 1 ? 14 : 12;
         // 256 x 128 tile, 8 waves of 64 x 64 on 16x16x32 MFMAs, wave-private epilogue, two workgroups per CU (round 2:
         // +9 % end to end over 24 / 28 on the 13x13 .. 52x52 maps)
         else if (halo_ok && BF16 && k.W <= 16) cfg = 68;     // 13x13: 128 x 128 tiles of 4 such waves fill the CUs more evenly
@@ -1312,6 +1533,10 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         // 16-wave 256x128 workgroup at 52x52, 7 % at 104x104)
         else if (halo_ok && (int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 80 * 1024) cfg = BF16 ? 69 : 28;
         else if (halo_ok && patch_bufs * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 26;
+        // plain bf16 1x1 layers on maps of 26 x 26 and larger: activations straight into MFMA operand registers (round 3: 104x104
+        // 65 -> 54 us, 52x52 37 -> 35, 26x26 30 -> 27; bit-identical to 88).  13x13 (K = 1024, four channel tiles re-read every
+        // pixel row) stays on the im2col kernel (25 vs 28 us).
+        else if (BF16 && k.ksize == 1 && k.stride == 1 && !k.upsample && !k.reorg && !k.out_f32 && (k.Cin * 2) % 128 == 0 && k.W > 16) cfg = 97;
         else cfg = (BF16 && !k.upsample && !k.reorg && !k.out_f32) ? 88 : 5;   // 88: 5 on 16x16x32 MFMAs with the register epilogue (+8 % on the 1x1 layers)
     }
     const bool plain = !k.upsample && !k.reorg && !k.out_f32;
@@ -1370,6 +1595,22 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 86: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 3, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 8 waves, 3-stage ring
         case 87: if (plain && k.Cout % 256 == 0) return launch_cfg<BF16, 256, 256, 4, 4, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 16 waves of 64 x 64, 128 KB
         case 88: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 3, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 81 with the register epilogue
+        case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97:   // direct-A 1x1 kernel: 8 / 4 waves, loads 2 / 3 / 4 K-steps ahead
+            if constexpr (BF16) {
+                if (k.ksize == 1 && k.stride == 1 && plain && (k.Cin * 2) % 128 == 0) {
+                    if (k.Cout <= 64 && cfg >= 96) return cfg & 1 ? launch_direct1x1<4, 4, 2, 2, false>(k, stream) : launch_direct1x1<8, 4, 2, 2, false>(k, stream);
+                    if (k.Cout <= 64) return cfg & 1 ? launch_direct1x1<4, 4, 3, 2>(k, stream) : launch_direct1x1<8, 4, 3, 2>(k, stream);
+                    if (cfg == 96) return launch_direct1x1<8, 8, 2, 2, false>(k, stream);
+                    if (cfg == 97) return launch_direct1x1<4, 8, 2, 2, false>(k, stream);
+                    if (cfg == 90) return launch_direct1x1<8, 8, 2, 2>(k, stream);
+                    if (cfg == 91) return launch_direct1x1<4, 8, 2, 2>(k, stream);
+                    if (cfg == 92) return launch_direct1x1<8, 8, 3, 2>(k, stream);
+                    if (cfg == 93) return launch_direct1x1<4, 8, 3, 2>(k, stream);
+                    if (cfg == 94) return launch_direct1x1<8, 8, 4, 2>(k, stream);
+                    return launch_direct1x1<4, 8, 4, 2>(k, stream);
+                }
+            }
+            return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
         case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);

@@ -1,6 +1,7 @@
 // Host side of libyolo_hip.so: weight ingestion (Darknet order, BN folding, K-major packing),
 // the static execution plan of yolov3.forward (reference yolo_v3/model.py:21-67 +
 // yolo_v3/utils/layer_utils.py:23-72) and the C-ABI entry points for the conv stack.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -972,10 +973,26 @@ extern "C" int yolo_conv_benchmark(YoloConv* c, int B, int H, int W, int with_re
         p.in = b; p.out = b + in_bytes;
         if (with_residual && !p.out_f32) { p.res = b + in_bytes + out_bytes; p.res_ld = L.cout; }
     };
+    int rc = YOLO_OK;
+    // YOLO_BENCH_STREAMS=<n> (n > 1): launches go round-robin over n streams (independent buffer sets), host-timed between two
+    // device synchronisations - the rate of the kernel when other launches fill its partly filled rounds and its ramps
+    static const int nstreams = [] { const char* e = getenv("YOLO_BENCH_STREAMS"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n > 8 ? 8 : n; }();
+    if (nstreams > 1 && R >= nstreams) {
+        hipStream_t st[8];
+        for (int i = 0; i < nstreams; ++i) YOLO_HIP_CHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        for (int i = 0; i < 2 * nstreams && rc == YOLO_OK; ++i) { set(i); rc = run_conv(L, p, st[i % nstreams]); }
+        (void)hipDeviceSynchronize();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters && rc == YOLO_OK; ++i) { set(i); rc = run_conv(L, p, st[i % nstreams]); }
+        if (hipDeviceSynchronize() != hipSuccess) { set_error("conv_benchmark: sync failed"); rc = YOLO_ERR_HIP; }
+        *avg_ms = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters);
+        for (int i = 0; i < nstreams; ++i) (void)hipStreamDestroy(st[i]);
+        (void)hipFree(base);
+        return rc;
+    }
     hipEvent_t e0, e1;
     YOLO_HIP_CHECK(hipEventCreate(&e0));
     YOLO_HIP_CHECK(hipEventCreate(&e1));
-    int rc = YOLO_OK;
     for (int i = 0; i < 3 && rc == YOLO_OK; ++i) { set(i); rc = run_conv(L, p, nullptr); }
     if (rc == YOLO_OK) {
         (void)hipEventRecord(e0, nullptr);
