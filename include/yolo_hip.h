@@ -53,9 +53,10 @@ int yolo_net_destroy(YoloNet* net);
 /* Bytes of activation workspace forward needs for a [B,H,W,3] input (0 on bad shape). */
 size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int W);
 /* images [B,H,W,3] f32 -> fm1 [B,H/32,W/32,3*(5+C)], fm2 [B,H/16,W/16,.], fm3 [B,H/8,W/8,.] f32.
- * Ordered on `stream` like a single launch.  From batch 12 up the images run as two (from batch 48: three) sub-batches
- * ("lanes"), one on `stream` and the others on streams the handle owns, forked and joined with events; the
- * result does not depend on the split.  YOLO_LANES=<1..4> in the environment overrides the lane count (1: none).
+ * Ordered on `stream` like a single launch.  By the work of the call in 416 x 416 images (B * H * W / 416^2): from 16 up the
+ * images run as two, from 56 up as three sub-batches ("lanes"), one on `stream` and the others on streams the handle owns,
+ * forked and joined with events; the result does not depend on the split.  YOLO_LANES=<1..8> in the environment overrides
+ * the lane count (1: none; never more lanes than images).
  * One forward at a time per handle: concurrent calls on one handle would share its side streams and plans. */
 int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, void* workspace,
                      size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream);
@@ -92,6 +93,11 @@ int yolo_conv_forward(YoloConv* conv, const float* in, int B, int H, int W, cons
 /* Measurement aid (no counterpart in the reference): average device time of `iters` launches of this
  * layer on internally allocated buffers of the layer's dtype.  Allocates and synchronises. */
 int yolo_conv_benchmark(YoloConv* conv, int B, int H, int W, int with_residual, int iters, float* avg_ms);
+
+/* Test / measurement aid (no counterpart in the reference): force tile configuration `cfg` of the conv kernels for every later
+ * conv launch of the process (ids: csrc/conv_igemm.hip launch_dtype; a layer the configuration does not apply to keeps the
+ * default choice); cfg < 0 restores the default choice.  The initial value is the environment variable YOLO_CONV_CFG, read once. */
+int yolo_debug_set_conv_cfg(int cfg);
 
 /* ---- replaces upsample_layer (layer_utils.py:67-72) for the exact-2x case the network uses. */
 int yolo_upsample2x(const float* in, int B, int H, int W, int C, float* out, void* stream);

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 ap = argparse.ArgumentParser(); ap.add_argument("--only", default="12"); ap.add_argument("--cfg", default=""); ap.add_argument("--batch", type=int, default=64)
 a = ap.parse_args()
-if a.cfg: os.environ["YOLO_CONV_CFG"] = a.cfg
+if a.cfg: os.environ["YOLO_CONV_CFG"] = a.cfg       # read once, at the library's first conv launch
 from yolo_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "yolo_amd", "lib", "libyolo_hip_stamps.so")
 L = _lib.lib()

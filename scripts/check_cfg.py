@@ -24,7 +24,7 @@ for cin, cout, B, H, W, resid in SHAPES:
     ws = _tensor.workspace(L.yolo_conv_workspace_bytes(h, B, H, W))
     outs = {}
     for cfg in [a.ref] + a.cfgs.split(","):
-        os.environ["YOLO_CONV_CFG"] = cfg
+        _lib.set_conv_cfg(cfg)
         out = torch.full((B, H, W, cout), float("nan"), device="cuda")
         _lib.check(L.yolo_conv_forward(h, x.data_ptr(), B, H, W, _tensor.ptr(r), out.data_ptr(), ws.data_ptr(), ws.numel(), _tensor.stream_ptr()))
         torch.cuda.synchronize()

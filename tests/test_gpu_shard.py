@@ -109,55 +109,95 @@ def _iou(a, b):
     return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter)
 
 
+def _iou_pairs(a, b):
+    """IoU of box a[i] with box b[i]."""
+    iw = np.maximum(0.0, np.minimum(a[:, 2], b[:, 2]) - np.maximum(a[:, 0], b[:, 0]))
+    ih = np.maximum(0.0, np.minimum(a[:, 3], b[:, 3]) - np.maximum(a[:, 1], b[:, 1]))
+    inter = iw * ih
+    return inter / np.maximum((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter, 1e-12)
+
+
 # stated bf16 tolerance (north_star "bf16 output within a stated tolerance"); measured values are in DESIGN.md section 2
 BF16_SCORE_TOL = 0.03       # |score difference| of matched detections (measured 0.015)
 BF16_MATCH_ALL = 0.80       # of ALL detections of one path, the share the other path reproduces with IoU >= 0.9 (measured 0.85 - 0.88)
+BF16_MATCH_ALL_50 = 0.90    # of ALL detections, the share reproduced at IoU >= 0.5 in the other side's list taken at score_thresh - BF16_SCORE_TOL (measured 0.927 - 0.95)
 BF16_MATCH_CLEAR = 0.95     # of the detections scoring >= score_thresh + BF16_SCORE_TOL, the share reproduced with IoU >= 0.5
 
 
 def test_bf16_detections_vs_fp32_oracle(net_bf16, oracle, oracle_params):
-    """bf16 conv stack (bf16 storage + MFMA inputs, f32 accumulate) against the fp32 CPU oracle at the detection level,
-    2 x 416 x 416, gpu_nms defaults (50, 0.5, 0.5), both directions (oracle -> bf16 and bf16 -> oracle):
-      * a matched pair has the same class, IoU >= the bound and scores within BF16_SCORE_TOL;
-      * at least BF16_MATCH_ALL of all detections are matched at IoU >= 0.9.  The synthetic random-init weights put
-        most of the ~300 detections per image just above the 0.5 threshold, so a score change of 0.01 - 0.03 moves some
-        across it and flips some greedy NMS choices between near-identical overlapping boxes: those are the unmatched ones;
-      * of the detections that clear the threshold by more than the score tolerance at least BF16_MATCH_CLEAR are matched
-        at the usual detection criterion IoU >= 0.5."""
+    """bf16 conv stack (bf16 storage + MFMA inputs, f32 accumulate) against the fp32 CPU oracle, 2 x 416 x 416.
+    (a) Candidate level, ALL 2 x 10647 boxes x 80 classes: |score - oracle score| <= BF16_SCORE_TOL everywhere (mean <= 1e-3),
+        decoded box vs oracle box of the same index: IoU >= 0.9 for >= 98 % of the boxes and >= 0.7 for every box.
+    (b) Detection level, gpu_nms defaults (50, 0.5, 0.5), ALL detections, both directions.  A detection is reproduced when the
+        other side holds one of the same class whose score differs by <= BF16_SCORE_TOL and whose box overlaps it with
+          * IoU >= 0.5 - the overlap above which NMS itself treats two boxes as one object - where the other side's list is taken
+            at score_thresh - BF16_SCORE_TOL, so that a score that merely crosses the threshold does not count as a miss:
+            asserted >= BF16_MATCH_ALL_50 of ALL detections of every image and direction, >= 0.95 pooled (measured 0.927 / 0.978);
+          * IoU >= 0.9 against the other side's list at the same threshold: asserted >= BF16_MATCH_ALL.  The seeded random-init
+            weights give every threshold hundreds of candidates within the bf16 score error of it and long chains of
+            near-identical overlapping boxes, so crossings and flipped greedy choices bound this share well below 1 for ANY
+            8-bit-mantissa path; widening the head's logit spread or moving the threshold into a gap of the oracle's score
+            histogram does not change that (gaps are ~1e-3 wide, the score error 2e-2; measured 0.89 - 0.92 for head gains
+            0.55 - 1.5, round 3) - which is why (a) and the IoU 0.5 share are the statements that carry weight.
+          * of the detections that clear the threshold by more than the tolerance, >= BF16_MATCH_CLEAR at IoU >= 0.5."""
     thr = 0.5
     img = np.random.default_rng(1).random((2, 416, 416, 3), dtype=np.float32)
-    ob, osc, ol, _, oc = [t.cpu().numpy() for t in net_bf16.detect(img, 50, thr, 0.5)]
-    worst = {"all@0.9": 1.0, "clear@0.5": 1.0, "dscore": 0.0}
+    # ---- (a) candidates
+    fms_ref = oracle.forward(oracle_params, img)
+    rbx, rcf, rpr = oracle.predict(fms_ref, oracle.YOLO_ANCHORS, (416, 416))
+    rsc = (rcf * rpr).astype(np.float32)
+    gbx, _, _, gsc = [t.cpu().numpy() for t in net_bf16.predict(net_bf16.forward(img), return_scores=True)]
+    dsc = np.abs(gsc - rsc)
+    biou = _iou_pairs(gbx.reshape(-1, 4), rbx.reshape(-1, 4))
+    cand = {"max_dscore": float(dsc.max()), "mean_dscore": float(dsc.mean()), "iou_ge_0.9": float((biou >= 0.9).mean()),
+            "iou_min": float(biou.min())}
+    print("bf16 vs fp32 oracle candidates:", cand)
+    assert cand["max_dscore"] <= BF16_SCORE_TOL and cand["mean_dscore"] <= 1e-3, cand
+    assert cand["iou_ge_0.9"] >= 0.98 and cand["iou_min"] >= 0.7, cand
+    # ---- (b) detections
+    det = {t: [x.cpu().numpy() for x in net_bf16.detect(img, 50, t, 0.5)] for t in (thr, thr - BF16_SCORE_TOL)}
+    worst = {"all@0.9": 1.0, "all@0.5_crossing_proof": 1.0, "clear@0.5": 1.0, "dscore": 0.0}
+    pooled = {"n": 0, "hit50": 0, "hit90": 0}
     for b in range(2):
-        rb, rs, rl = oracle.detect(oracle_params, oracle.YOLO_ANCHORS, img[b:b + 1], 80, 50, thr, 0.5)
-        m = int(oc[b])
-        gb, gs, gl = ob[b, :m], osc[b, :m], ol[b, :m]
-        assert len(rl) > 20 and m > 20
+        ref = {t: oracle.gpu_nms(rbx[b], rsc[b], 80, 50, t, 0.5) for t in (thr, thr - BF16_SCORE_TOL)}
+        got = {}
+        for t, (ob, osc, ol, _, oc) in det.items():
+            m = int(oc[b])
+            got[t] = (ob[b, :m], osc[b, :m], ol[b, :m])
+        assert len(ref[thr][2]) > 20 and len(got[thr][2]) > 20
 
-        def matched(ab, as_, al, bb, bs, bl, iou_min, only_clear):
+        def matched(A, Bq, iou_min, only_clear):
+            ab, as_, al = A
+            bb, bs, bl = Bq
             hit, n, dmax = 0, 0, 0.0
             for i in range(len(al)):
                 if only_clear and as_[i] < thr + BF16_SCORE_TOL:
                     continue
                 n += 1
-                cand = np.nonzero(bl == al[i])[0]
-                if len(cand) == 0:
+                cand_i = np.nonzero(bl == al[i])[0]
+                if len(cand_i) == 0:
                     continue
-                iou = _iou(ab[i], bb[cand])
-                j = int(np.argmax(iou))
-                d = abs(float(bs[cand[j]]) - float(as_[i]))
-                if iou[j] >= iou_min and d <= BF16_SCORE_TOL:
+                iou = _iou(ab[i], bb[cand_i])
+                ok = (iou >= iou_min) & (np.abs(bs[cand_i] - as_[i]) <= BF16_SCORE_TOL)
+                if ok.any():
                     hit += 1
-                    dmax = max(dmax, d)
-            return hit / max(1, n), dmax, n
-        for (A, Bq) in (((rb, rs, rl), (gb, gs, gl)), ((gb, gs, gl), (rb, rs, rl))):
-            f9, d1, _ = matched(*A, *Bq, 0.9, False)
-            f5, d2, nclear = matched(*A, *Bq, 0.5, True)
+                    dmax = max(dmax, float(np.abs(bs[cand_i][ok] - as_[i]).min()))
+            return hit, n, dmax
+        lo = thr - BF16_SCORE_TOL
+        for A, B_same, B_low in ((ref[thr], got[thr], got[lo]), (got[thr], ref[thr], ref[lo])):
+            h9, n, d1 = matched(A, B_same, 0.9, False)
+            h5, _, d2 = matched(A, B_low, 0.5, False)
+            hc, nclear, d3 = matched(A, B_same, 0.5, True)
             assert nclear > 20
-            worst["all@0.9"], worst["clear@0.5"] = min(worst["all@0.9"], f9), min(worst["clear@0.5"], f5)
-            worst["dscore"] = max(worst["dscore"], d1, d2)
-        print("image %d: oracle %d detections, bf16 %d" % (b, len(rl), m))
-    print("bf16 vs fp32 oracle detections:", worst)
+            worst["all@0.9"] = min(worst["all@0.9"], h9 / n)
+            worst["all@0.5_crossing_proof"] = min(worst["all@0.5_crossing_proof"], h5 / n)
+            worst["clear@0.5"] = min(worst["clear@0.5"], hc / nclear)
+            worst["dscore"] = max(worst["dscore"], d1, d2, d3)
+            pooled["n"] += n; pooled["hit50"] += h5; pooled["hit90"] += h9
+        print("image %d: oracle %d detections, bf16 %d" % (b, len(ref[thr][2]), len(got[thr][2])))
+    print("bf16 vs fp32 oracle detections (worst image / direction):", worst, "pooled:", pooled)
+    assert worst["all@0.5_crossing_proof"] >= BF16_MATCH_ALL_50, worst
+    assert pooled["hit50"] >= 0.95 * pooled["n"], pooled           # over both images and directions (measured 0.978)
     assert worst["all@0.9"] >= BF16_MATCH_ALL and worst["clear@0.5"] >= BF16_MATCH_CLEAR, worst
 
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "yolo_conv_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "yolo_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "yolo_conv_benchmark": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "yolo_debug_set_conv_cfg": (_i, [_i]),
     "yolo_upsample2x": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "yolo_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yolo_reorg_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -73,6 +74,11 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def set_conv_cfg(cfg):
+    """Test / measurement aid: force a conv tile configuration (None or < 0: the library's own choice)."""
+    check(lib().yolo_debug_set_conv_cfg(-1 if cfg is None else int(cfg)))
 
 
 class YoloHipError(RuntimeError):

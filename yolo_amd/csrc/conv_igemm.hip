@@ -17,6 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
 #include <type_traits>
 #include "common.h"
 
@@ -924,6 +927,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
 #endif
 }
 
+#ifdef YOLO_EXPERIMENTAL_TILINGS
 // ---- 3x3 stride-1 convolution, 256x256 tile, ping-pong wave rows ("p8", bf16 only) -----------------------------------
 // The LDS-resident patch of conv3x3_halo_kernel under the GEMM schedule measured in scripts/probe/gemm8p.hip (1.0-1.2
 // PFLOP/s on random bf16 data against ~0.83 for the 128x128 / two-workgroup structure above):
@@ -1238,6 +1242,8 @@ static int launch_p8(const ConvK& k, hipStream_t stream) {
     return YOLO_OK;
 }
 
+#endif  // YOLO_EXPERIMENTAL_TILINGS
+
 // ---- 1x1 stride-1 convolution with the activations loaded straight into MFMA operand registers ("direct-A", bf16) ----
 // The im2col kernel stages A and B through LDS by LDS-DMA; on the 1x1 layers (4 - 16 K-steps per tile) it is bound by the
 // issue cost and the landing latency of those pieces, not by HBM or the matrix pipe (round 3: dropping either operand's
@@ -1473,20 +1479,59 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
     }
 }
 
-// Tile configurations.  YOLO_CONV_CFG=<id> (environment) forces one for experiments and tests.
+// ---- tile configurations -------------------------------------------------------------------------------------------------
+// The shipped library holds the configurations the default choice below can pick plus a few alternates the parity tests use as
+// independent cross-checks (5: im2col + LDS epilogue, 81 / 88: wave-private / register epilogue, 96: 8-wave direct-A, 75 = 72 / 73 /
+// 74: the halo tiles with the register epilogue).  yolo_debug_set_conv_cfg(id) forces one (tests, scripts); the environment
+// variable YOLO_CONV_CFG is read ONCE, when the library first launches a conv, as the initial value.  Everything that was measured
+// and rejected (ping-pong tile, 192- / 320-row tiles, deeper rings, ...) is compiled only with -DYOLO_EXPERIMENTAL_TILINGS
+// (make XP=1 -> libyolo_hip_xp.so), which also reads YOLO_HALO_CFG / YOLO_IGEMM_CFG ("<W>=<cfg>,..." / "<k>x<Wo>=<cfg>,...").
+static std::atomic<int> g_forced_cfg{-2};              // -2: not initialised, -1: default choice
+static int forced_cfg() {
+    int v = g_forced_cfg.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv("YOLO_CONV_CFG");
+        v = e ? atoi(e) : -1;
+        if (v < -1) v = -1;
+        int expect = -2;
+        g_forced_cfg.compare_exchange_strong(expect, v);
+        v = g_forced_cfg.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" int yolo_debug_set_conv_cfg(int cfg) {
+    g_forced_cfg.store(cfg < 0 ? -1 : cfg, std::memory_order_relaxed);
+    return YOLO_OK;
+}
+
+#ifdef YOLO_EXPERIMENTAL_TILINGS
+static int env_map_cfg(const char* var, int ksize, int w) {       // "<W>=<cfg>,..." (ksize 0) or "<k>x<Wo>=<cfg>,..."
+    static std::mutex mu;
+    static std::map<std::string, std::string> cache;
+    std::string text;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(var);
+        if (it == cache.end()) { const char* e = getenv(var); it = cache.emplace(var, e ? e : "").first; }
+        text = it->second;
+    }
+    for (const char* q = text.c_str(); q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+        int ks = 0, ww = 0, c = 0;
+        if (ksize == 0 ? (sscanf(q, "%d=%d", &ww, &c) == 2 && ww == w) : (sscanf(q, "%dx%d=%d", &ks, &ww, &c) == 3 && ks == ksize && ww == w)) return c;
+    }
+    return -1;
+}
+#endif
+
 template <bool BF16>
 static int launch_dtype(const ConvK& k, hipStream_t stream) {
-    const char* forced = getenv("YOLO_CONV_CFG");              // read per call: the tests toggle it
-    int cfg = forced ? atoi(forced) : -1;
+    int cfg = forced_cfg();
     const int sz = BF16 ? 2 : 4;
-    const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && !k.upsample && !k.out_f32 && !k.reorg;
-    if (const char* hm = getenv("YOLO_HALO_CFG")) {             // experiments: "<W>=<cfg>,..." for the 3x3 stride-1 layers of width W
-        if (halo_ok && cfg < 0)
-            for (const char* q = hm; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
-                int w = 0, c = 0;
-                if (sscanf(q, "%d=%d", &w, &c) == 2 && w == k.W) { cfg = c; break; }
-            }
-    }
+    const bool plain = !k.upsample && !k.reorg && !k.out_f32;
+    const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && plain;
+    const bool direct_ok = BF16 && k.ksize == 1 && k.stride == 1 && plain && (k.Cin * 2) % 128 == 0;
+#ifdef YOLO_EXPERIMENTAL_TILINGS
+    if (halo_ok && cfg < 0) cfg = env_map_cfg("YOLO_HALO_CFG", 0, k.W);
     if (cfg >= 43 && cfg <= 46) {                               // ping-pong tile on the small (43, 44) / large (45, 46) maps only
         if constexpr (BF16) {
             if (halo_ok && k.Cout % 256 == 0 && (cfg <= 44 ? k.W <= 32 : k.W > 32) && 256 + 2 * k.W + 2 <= 504)
@@ -1498,21 +1543,16 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         if (halo_ok && k.W <= 32) cfg = cfg == 53 ? 50 : cfg == 54 ? 51 : cfg == 55 ? 60 : 61;
         else cfg = -1;
     }
-    if (cfg == 75) cfg = !halo_ok ? -1 : k.W <= 16 ? 73 : k.W <= 52 ? 72 : 74;   // the shipped tile choice with the register epilogue
-    if (cfg == 67) cfg = !halo_ok ? -1 : k.W <= 32 ? 62 : 63;    // the shipped tiling with the wave-private epilogue
+    if (cfg == 67) cfg = !halo_ok ? -1 : k.W <= 32 ? 62 : 63;    // the round-1 tiling with the wave-private epilogue
     if (cfg >= 65 && cfg <= 66) {                               // ... and up to 52 x 52
         if (halo_ok && k.W <= 52) cfg = cfg == 65 ? 60 : 61;
         else cfg = -1;
     }
-    if (const char* im = getenv("YOLO_IGEMM_CFG")) {            // experiments: "<ksize>x<Wo>=<cfg>,..." for the layers of the im2col kernel
-        if (!halo_ok && cfg < 0 && k.Cout > 64)
-            for (const char* q = im; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
-                int ks = 0, w = 0, c = 0;
-                if (sscanf(q, "%dx%d=%d", &ks, &w, &c) == 3 && ks == k.ksize && w == k.Wo) { cfg = c; break; }
-            }
-    }
+    if (!halo_ok && cfg < 0 && k.Cout > 64) cfg = env_map_cfg("YOLO_IGEMM_CFG", k.ksize, k.Wo);
+#endif
+    if (cfg == 75) cfg = !halo_ok ? -1 : k.W <= 16 ? 73 : k.W <= 52 ? 72 : 74;   // the shipped tile choice with the register epilogue
     if (cfg >= 80 && cfg < 90 && (halo_ok || k.Cout <= 64)) cfg = -1;
-    if (cfg >= 90 && cfg < 100 && !(k.ksize == 1 && k.stride == 1 && !k.upsample && !k.reorg && !k.out_f32 && BF16 && (k.Cin * 2) % 128 == 0)) cfg = -1;
+    if (cfg >= 90 && cfg < 100 && !direct_ok) cfg = -1;
     if (cfg >= 20 && cfg < 80 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
@@ -1523,7 +1563,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         const int prows256 = 256 + 2 * k.W + 2 + 7;
         const int patch_bufs = k.Cin * sz > 128 ? 2 : 1;
         if (k.Cout <= 32) cfg = 10;
-        else if (k.Cout <= 64) cfg = (BF16 && k.ksize == 1 && k.stride == 1 && !k.upsample && !k.reorg && !k.out_f32 && (k.Cin * 2) % 128 == 0) ? 97 : k.ksize == 1 ? 14 : 12;
+        else if (k.Cout <= 64) cfg = direct_ok ? 97 : k.ksize == 1 ? 14 : 12;
         // 256 x 128 tile, 8 waves of 64 x 64 on 16x16x32 MFMAs, wave-private epilogue, two workgroups per CU (round 2:
         // +9 % end to end over 24 / 28 on the 13x13 .. 52x52 maps)
         else if (halo_ok && BF16 && k.W <= 16) cfg = 68;     // 13x13: 128 x 128 tiles of 4 such waves fill the CUs more evenly
@@ -1536,11 +1576,37 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         // plain bf16 1x1 layers on maps of 26 x 26 and larger: activations straight into MFMA operand registers (round 3: 104x104
         // 65 -> 54 us, 52x52 37 -> 35, 26x26 30 -> 27; bit-identical to 88).  13x13 (K = 1024, four channel tiles re-read every
         // pixel row) stays on the im2col kernel (25 vs 28 us).
-        else if (BF16 && k.ksize == 1 && k.stride == 1 && !k.upsample && !k.reorg && !k.out_f32 && (k.Cin * 2) % 128 == 0 && k.W > 16) cfg = 97;
-        else cfg = (BF16 && !k.upsample && !k.reorg && !k.out_f32) ? 88 : 5;   // 88: 5 on 16x16x32 MFMAs with the register epilogue (+8 % on the 1x1 layers)
+        else if (direct_ok && k.W > 16) cfg = 97;
+        else cfg = (BF16 && plain) ? 88 : 5;   // 88: 5 on 16x16x32 MFMAs with the register epilogue (+8 % on the 1x1 layers)
     }
-    const bool plain = !k.upsample && !k.reorg && !k.out_f32;
     switch (cfg) {
+        case 5: return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);     // 8 waves, 2 blocks/CU
+        case 24: return launch_halo<BF16, 128, 128, 4, 2>(k, stream);      // 8 waves, 2 blocks/CU
+        case 26: return launch_halo<BF16, 256, 128, 8, 2>(k, stream);      // 16 waves, 1 block/CU
+        case 28: return launch_halo<BF16, 128, 128, 4, 2, true>(k, stream);   // single patch buffer: 2 blocks/CU up to W ~ 60
+        // 256 x 128 tile, 8 waves of 64 x 64 (half the LDS fragment reads and LDS-DMA pieces per MFMA of 24 / 28), single
+        // patch buffer + wave-private epilogue: <= 80 KB of LDS up to W = 52 and <= 128 VGPRs, so two workgroups per CU
+        case 61: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 0, 4>(k, stream);
+        case 68: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2>(k, stream);   // 4 waves of 64 x 64, up to three workgroups per CU
+        case 69: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 0, 1>(k, stream);   // 28 on 16x16x32 with the wave-private epilogue
+        case 72: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 3, 4>(k, stream);   // 61 / 68 / 69 with the register epilogue
+        case 73: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 3, 2>(k, stream);
+        case 74: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 3, 1>(k, stream);
+        // im2col kernel on 16x16x32 MFMAs with the wave-private (81) / register (88) epilogue (plain and residual layers only)
+        case 81: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 88: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 3, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 96: case 97:                                                   // direct-A 1x1 kernel, 8 / 4 waves per workgroup
+            if constexpr (BF16) {
+                if (direct_ok) {
+                    if (k.Cout <= 64) return cfg & 1 ? launch_direct1x1<4, 4, 2, 2, false>(k, stream) : launch_direct1x1<8, 4, 2, 2, false>(k, stream);
+                    return cfg & 1 ? launch_direct1x1<4, 8, 2, 2, false>(k, stream) : launch_direct1x1<8, 8, 2, 2, false>(k, stream);
+                }
+            }
+            return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
+        case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
+        case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
+#ifdef YOLO_EXPERIMENTAL_TILINGS
         case 0: return launch_cfg<BF16, 128, 128, 2, 2, 2>(k, stream);     // 2 blocks/CU
         case 1: return launch_cfg<BF16, 256, 128, 4, 2, 3>(k, stream);     // 8 waves, 3-stage ring, 1 block/CU
         case 2: return launch_cfg<BF16, 128, 128, 2, 2, 3>(k, stream);     // 4 waves, 3-stage ring, 1 block/CU
@@ -1548,36 +1614,25 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
             if (k.Cout % 256 == 0) return launch_cfg<BF16, 128, 256, 2, 4, 3>(k, stream);
             return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
         case 4: return launch_cfg<BF16, 256, 128, 4, 2, 2>(k, stream);
+        case 6: return launch_cfg<BF16, 128, 128, 2, 4, 2>(k, stream);
+        case 11: return launch_cfg<BF16, 256, 64, 4, 1, 2>(k, stream);
         case 20: return launch_halo<BF16, 256, 128, 4, 2>(k, stream);
         case 21: return launch_halo<BF16, 128, 128, 2, 2>(k, stream);
-        case 5: return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);     // 8 waves, 2 blocks/CU
-        case 6: return launch_cfg<BF16, 128, 128, 2, 4, 2>(k, stream);
-        case 24: return launch_halo<BF16, 128, 128, 4, 2>(k, stream);      // 8 waves, 2 blocks/CU
         case 25: return launch_halo<BF16, 128, 128, 2, 4>(k, stream);
-        case 26: return launch_halo<BF16, 256, 128, 8, 2>(k, stream);      // 16 waves, 1 block/CU
         case 27: return launch_halo<BF16, 256, 128, 4, 4>(k, stream);
-        case 28: return launch_halo<BF16, 128, 128, 4, 2, true>(k, stream);   // single patch buffer: 2 blocks/CU up to W ~ 60
-        // 256 x 128 tile, 8 waves of 64 x 64 (half the LDS fragment reads and LDS-DMA pieces per MFMA of 24 / 28), single
-        // patch buffer + two-pass epilogue staging: <= 80 KB of LDS up to W = 52 and <= 128 VGPRs, so two workgroups per CU
         case 50: return launch_halo<BF16, 256, 128, 4, 2, true, 32, 2, 4>(k, stream);
         case 51: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 2, 4>(k, stream);   // the same out of 16x16x32 MFMAs
         case 52: return launch_halo<BF16, 256, 128, 4, 2, false, 32, 2, 2>(k, stream);  // two patch buffers, one workgroup per CU
         case 60: return launch_halo<BF16, 256, 128, 4, 2, true, 32, 0, 4>(k, stream);   // 50 / 51 with the wave-private epilogue
-        case 61: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 0, 4>(k, stream);
-        case 62: return launch_halo<BF16, 128, 128, 4, 2, false, 32, 0, 1>(k, stream);  // the shipped 24 / 28 with the wave-private epilogue
+        case 62: return launch_halo<BF16, 128, 128, 4, 2, false, 32, 0, 1>(k, stream);  // 24 / 28 with the wave-private epilogue
         case 63: return launch_halo<BF16, 128, 128, 4, 2, true, 32, 0, 1>(k, stream);
         case 64: return launch_halo<BF16, 128, 128, 2, 2, true, 32, 0, 2>(k, stream);   // 4 waves of 64 x 64, up to four workgroups per CU
-        case 68: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2>(k, stream);
-        case 72: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 3, 4>(k, stream);   // 61 / 68 / 69 with the register epilogue
-        case 73: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 3, 2>(k, stream);
-        case 74: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 3, 1>(k, stream);
         case 70: case 71:                                                   // bf16 only (48 / 80 rows per wave need 16-row MFMA tiles)
             if constexpr (BF16) {
                 if (cfg == 70) return launch_halo<true, 192, 128, 4, 2, true, 16, 0, 4>(k, stream);   // 48 x 64 per wave: 904 instead of 676 tiles at 26x26 / batch 64
                 return launch_halo<true, 320, 128, 4, 2, true, 16, 0, 2>(k, stream);                  // 80 x 64 per wave (one workgroup per CU)
             }
             return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
-        case 69: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 0, 1>(k, stream);   // 28 on 16x16x32 with the wave-private epilogue
         case 40: case 41: case 42:                                          // 256 / 192 / 128 x 256 ping-pong tile, bf16 only
             if constexpr (BF16) {
                 if (k.Cout % 256 == 0) return cfg == 40 ? launch_p8<4>(k, stream) : cfg == 41 ? launch_p8<3>(k, stream) : launch_p8<2>(k, stream);
@@ -1585,23 +1640,17 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
             return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 34: return launch_halo<BF16, 128, 128, 4, 2, false, 16>(k, stream);   // 24 / 28 out of 16x16x32 MFMAs
         case 38: return launch_halo<BF16, 128, 128, 4, 2, true, 16>(k, stream);
-        // im2col kernel with 64 x 64 waves / wave-private epilogue (plain and residual layers only)
         case 80: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 32, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 5 + wave epilogue
-        case 81: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
         case 82: if (plain) return launch_cfg<BF16, 256, 128, 4, 2, 2, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 96 KB: 1 workgroup / CU
         case 83: if (plain) return launch_cfg<BF16, 256, 128, 4, 2, 3, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 3-stage ring, 144 KB
         case 84: if (plain) return launch_cfg<BF16, 128, 128, 2, 2, 2, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 4 waves of 64 x 64, 2 workgroups / CU
         case 85: if (plain) return launch_cfg<BF16, 128, 128, 2, 2, 3, 16, 0, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 3-stage ring, 96 KB
         case 86: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 3, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 8 waves, 3-stage ring
         case 87: if (plain && k.Cout % 256 == 0) return launch_cfg<BF16, 256, 256, 4, 4, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 16 waves of 64 x 64, 128 KB
-        case 88: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 3, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 81 with the register epilogue
-        case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97:   // direct-A 1x1 kernel: 8 / 4 waves, loads 2 / 3 / 4 K-steps ahead
+        case 90: case 91: case 92: case 93: case 94: case 95:              // direct-A 1x1 kernel with the k-chunks permuted (adjacent pieces per lane), deeper prefetch
             if constexpr (BF16) {
-                if (k.ksize == 1 && k.stride == 1 && plain && (k.Cin * 2) % 128 == 0) {
-                    if (k.Cout <= 64 && cfg >= 96) return cfg & 1 ? launch_direct1x1<4, 4, 2, 2, false>(k, stream) : launch_direct1x1<8, 4, 2, 2, false>(k, stream);
+                if (direct_ok) {
                     if (k.Cout <= 64) return cfg & 1 ? launch_direct1x1<4, 4, 3, 2>(k, stream) : launch_direct1x1<8, 4, 3, 2>(k, stream);
-                    if (cfg == 96) return launch_direct1x1<8, 8, 2, 2, false>(k, stream);
-                    if (cfg == 97) return launch_direct1x1<4, 8, 2, 2, false>(k, stream);
                     if (cfg == 90) return launch_direct1x1<8, 8, 2, 2>(k, stream);
                     if (cfg == 91) return launch_direct1x1<4, 8, 2, 2>(k, stream);
                     if (cfg == 92) return launch_direct1x1<8, 8, 3, 2>(k, stream);
@@ -1611,13 +1660,10 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
                 }
             }
             return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
-        case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
-        case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
-        case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
-        case 11: return launch_cfg<BF16, 256, 64, 4, 1, 2>(k, stream);
+#endif
         default: break;
     }
-    set_error("conv: unknown tile configuration %d", cfg);
+    set_error("conv: unknown tile configuration %d (experimental tilings need the XP build)", cfg);
     return YOLO_ERR_ARG;
 }
 
