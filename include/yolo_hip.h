@@ -101,6 +101,9 @@ int yolo_debug_set_conv_cfg(int cfg);
 
 /* ---- replaces upsample_layer (layer_utils.py:67-72) for the exact-2x case the network uses. */
 int yolo_upsample2x(const float* in, int B, int H, int W, int C, float* out, void* stream);
+/* ... and for any output size: tf.image.resize_nearest_neighbor(align_corners=True) of TF 1.x (layer_utils.py:71):
+ * src = min(round(dst * (in - 1) / (out - 1)), in - 1) per axis.  in [B,H,W,C] f32 -> out [B,Ho,Wo,C] f32. */
+int yolo_upsample_nearest(const float* in, int B, int H, int W, int C, int Ho, int Wo, float* out, void* stream);
 
 /* ---- decode: replaces yolov3.reorg_layer + yolov3.predict (yolo_v3/model.py:69-153) and,
  * when scores != NULL, the caller's `pred_confs * pred_probs` (yolo_v3/test_single_image.py:38).
@@ -138,7 +141,9 @@ int yolo_nms(const float* boxes, const float* scores, int B, int n, int class_nu
  * process ends.  Sizes whose yolo_nms_workspace_bytes exceeds YOLO_NMS_STATIC_BYTES (about B * n * class_num > 2 M,
  * e.g. more than one 608 x 608 image of 80 classes) are refused with YOLO_ERR_UNSUPPORTED.  Calls no hipMalloc /
  * hipFree.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
- * threads) race; serialise them. */
+ * threads) race; serialise them.  The FIRST call on a device resolves that device's copy of the array (hipGetSymbolAddress,
+ * which loads the code object) under a lock: make one call per device - any valid small problem - before capturing a graph
+ * or entering a loop that must not touch the runtime; later calls only enqueue kernels and a memset node. */
 #define YOLO_NMS_STATIC_BYTES ((size_t)16 << 20)
 int yolo_nms_static(const float* boxes, const float* scores, int B, int n, int class_num, int max_boxes,
                     float score_thresh, float iou_thresh, int mode, float* out_boxes, float* out_scores,
@@ -208,12 +213,13 @@ int yolo_reorg2x(const float* in, int B, int H, int W, int C, float* out, void* 
  * input pixels, probs float32 = softmax(classes) * sigmoid(conf), exactly the reference's numpy dtypes. */
 int yolo2_decode(const float* logits, int B, int S, int NB, int C, int image_size, const double* anchors,
                  double* boxes, float* probs, void* stream);
-/* yolo2_nms: out_counts[i] <= max_det is the number of rows written for image i; max_det + 1 means more detections survived
- * than rows were given (the reference has no cap: call again with max_det = n * C, which always suffices). */
+/* yolo2_nms: out_counts[i] <= max_det is the number of rows written for image i, always.  out_truncated (optional, [B]) is set
+ * to 1 for an image with more survivors than rows (degenerate boxes; the reference has no cap: call again with max_det = n * C,
+ * which always suffices), else 0. */
 size_t yolo2_nms_workspace_bytes(int B, int n, int C);
 int yolo2_nms(const double* boxes, const float* probs, int B, int n, int C, float threshold, double iou_thresh,
               int max_det, int32_t* out_counts, int32_t* out_cls, double* out_boxes, float* out_probs,
-              int32_t* out_flat, void* workspace, size_t workspace_bytes, void* stream);
+              int32_t* out_flat, int32_t* out_truncated, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

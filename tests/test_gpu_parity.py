@@ -394,8 +394,14 @@ def test_layer_utils_compose_like_forward(net_f32, torch_cuda, oracle, weight_st
     x = np.random.default_rng(2).normal(size=(2, 5, 7, 8)).astype(np.float32)
     up = lu.upsample_layer(x, [2, 10, 14, 8])
     np.testing.assert_array_equal(up.cpu().numpy(), oracle.upsample_layer(x, (2, 10, 14, 8)))
+    # any output size (layer_utils.py:67-72 takes an arbitrary out_shape): TF 1.x align_corners rounding, bit-exact vs the oracle
+    for shape, out_hw in (((2, 5, 7, 8), (15, 21)), ((2, 5, 7, 8), (5, 7)), ((1, 13, 13, 6), (19, 31)), ((3, 4, 9, 5), (1, 1)),
+                          ((1, 1, 1, 4), (3, 2)), ((2, 26, 26, 12), (13, 40)), ((1, 7, 3, 3), (100, 99))):
+        xx = np.random.default_rng(sum(shape)).normal(size=shape).astype(np.float32)
+        tgt = [shape[0], out_hw[0], out_hw[1], shape[3]]
+        np.testing.assert_array_equal(lu.upsample_layer(xx, tgt).cpu().numpy(), oracle.upsample_layer(xx, tuple(tgt)))
     with pytest.raises(ValueError):
-        lu.upsample_layer(x, [2, 15, 21, 8])
+        lu.upsample_layer(x, [2, 0, 21, 8])
 
 
 def test_detect_end_to_end_vs_oracle(net_f32, oracle, oracle_params):
@@ -433,6 +439,31 @@ def test_detect_post_fused_equals_separate_calls(net_bf16, net_f32):
                 m = int(ref[4][b])
                 for r, g in zip(ref[:4], got[:4]):
                     assert torch.equal(r[b, :m], g[b, :m])
+
+
+def test_detect_with_more_than_250_classes(torch_cuda, oracle):
+    """The fused detect path holds <= 250 classes; the reference has no limit (nms_utils.py:7): a 300-class model goes through
+    predict + gpu_nms_batched inside detect() and gives the oracle's detections (fp32, same boxes / labels, scores to 1e-5)."""
+    from yolo_amd import weights
+    from yolo_amd.model import yolov3
+    C = 300
+    stream = weights.synth_darknet_stream(C, seed=5)
+    m = yolov3(C, oracle.YOLO_ANCHORS, dtype="fp32").load_weight_stream(stream)
+    img = np.random.default_rng(8).random((2, 64, 96, 3), dtype=np.float32)
+    ob, osc, ol, oi, oc = [t.cpu().numpy() for t in m.detect(img, 7, 0.02, 0.5)]
+    params = oracle.split_darknet_stream(oracle.yolov3_conv_specs(C), stream)
+    fms = oracle.forward(params, img, C)
+    rbx, rcf, rpr = oracle.predict(fms, oracle.YOLO_ANCHORS, (64, 96), C)
+    hit = tot = 0
+    for b in range(2):
+        _, _, rl, ri = oracle.gpu_nms(rbx[b], rcf[b] * rpr[b], C, 7, 0.02, 0.5, return_indices=True)
+        n = int(oc[b])
+        got = {(int(l), int(i)) for l, i in zip(ol[b, :n], oi[b, :n])}
+        ref = {(int(l), int(i)) for l, i in zip(rl, ri)}
+        assert int(ol[b, :n].max()) > 250 and abs(n - len(ref)) <= max(2, len(ref) // 50)
+        hit += len(got & ref)
+        tot += len(ref)
+    assert tot > 50 and hit >= 0.97 * tot, (hit, tot)      # scores differ in the last bits: sets with tolerance, as above
 
 
 def test_detect_post_argument_errors(net_f32):

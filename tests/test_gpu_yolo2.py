@@ -243,7 +243,7 @@ def test_detect_resizes_uint8_images_on_gpu(detector, v2_f32):
 def test_nms_degenerate_boxes_survive_in_several_classes(detector, O2):
     """A zero-size box has IoU 0/0 = NaN with itself, and `NaN > 0.5` is false (Detector.py:76, :107-115): every class of
     it that passes the threshold survives, as in the reference, so one box can give several rows.  With the default of
-    n rows that can overflow: the kernel reports max_det + 1 and calc_output_batched repeats with n * C rows."""
+    n rows that can overflow: the kernel sets out_truncated (counts stay <= the rows written) and Detector.nms repeats with n * C rows."""
     import warnings
     rng = np.random.default_rng(19)
     S, NB, C = 13, 5, 20
@@ -258,11 +258,16 @@ def test_nms_degenerate_boxes_survive_in_several_classes(detector, O2):
         rc, rb, rp, rf = O2.nms_from_decoded(boxes[0], probs[0])
     n = S * S * NB
     assert len(rc) == 2 * n
-    counts, cls, ob, op, flat = detector.nms(boxes, probs)               # default n rows: cut, and reported as cut
-    assert int(counts[0]) == n + 1
+    counts, cls, ob, op, flat = detector.nms(boxes, probs, n)            # explicit n rows: cut there, and reported as cut
+    assert int(counts[0]) == n and bool(detector.last_truncated[0])      # the count never exceeds the rows written
+    np.testing.assert_array_equal(flat[0, :n].cpu().numpy(), rf[:n])
     counts, cls, ob, op, flat = detector.nms(boxes, probs, n * C)
+    assert not bool(detector.last_truncated.any())
     m = int(counts[0])
     assert m == 2 * n
+    c2, _, _, _, f2 = detector.nms(boxes, probs)                         # default: repeats itself with n * C rows
+    assert int(c2[0]) == 2 * n and not bool(detector.last_truncated.any())
+    np.testing.assert_array_equal(f2[0, :m].cpu().numpy(), rf)
     np.testing.assert_array_equal(flat[0, :m].cpu().numpy(), rf)
     np.testing.assert_array_equal(cls[0, :m].cpu().numpy(), rc)
     np.testing.assert_array_equal(op[0, :m].cpu().numpy(), rp)

@@ -53,6 +53,54 @@ def test_nms_static_equals_nms_two_calls(torch_cuda):
                 assert np.array_equal(g[b, :m], r[b, :m])
 
 
+def test_nms_static_allocates_nothing_and_replays_in_a_graph(torch_cuda):
+    """After one warm call on the device (which resolves the device array), a call changes neither the driver's free-memory
+    figure nor torch's allocator statistics, and it can be captured into a HIP graph and replayed: the replay on new inputs
+    in the same buffers gives what yolo_nms gives."""
+    import torch
+    from yolo_amd import _lib, _tensor
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    B, n, C, mb = 1, 2000, 5, 10
+    boxes, scores = _case(rng, B, n, C)
+    _run(L, True, boxes, scores, C, mb, 0.3, 0.5, 0)                  # warm call
+    bd, sd = _tensor.as_dev_f32(boxes), _tensor.as_dev_f32(scores)
+    cap = C * mb
+    outs = [torch.zeros((B, cap, 4), device="cuda"), torch.zeros((B, cap), device="cuda"),
+            torch.zeros((B, cap), dtype=torch.int32, device="cuda"), torch.zeros((B, cap), dtype=torch.int32, device="cuda"),
+            torch.zeros((B,), dtype=torch.int32, device="cuda")]
+
+    def call(stream_ptr):
+        _lib.check(L.yolo_nms_static(bd.data_ptr(), sd.data_ptr(), B, n, C, mb, 0.3, 0.5, 0, *[o.data_ptr() for o in outs], stream_ptr))
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    reserved0, allocs0 = torch.cuda.memory_reserved(), torch.cuda.memory_stats().get("allocation.all.allocated", 0)
+    call(_tensor.stream_ptr())
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0 and torch.cuda.memory_reserved() == reserved0
+    assert torch.cuda.memory_stats().get("allocation.all.allocated", 0) == allocs0
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        call(torch.cuda.current_stream().cuda_stream)
+        g.capture_end()
+    torch.cuda.synchronize()
+    boxes2, scores2 = _case(rng, B, n, C)                            # new inputs in the captured buffers
+    bd.copy_(torch.from_numpy(boxes2))
+    sd.copy_(torch.from_numpy(scores2))
+    for o in outs:
+        o.fill_(-3)
+    g.replay()
+    torch.cuda.synchronize()
+    ref = _run(L, False, boxes2, scores2, C, mb, 0.3, 0.5, 0)
+    m = int(ref[4][0])
+    assert m > 0 and int(outs[4][0]) == m
+    for o, r in zip(outs[:4], ref[:4]):
+        assert np.array_equal(o[0, :m].cpu().numpy(), r[0, :m])
+
+
 def test_nms_static_rejects_oversize(torch_cuda):
     import torch
     from yolo_amd import _lib

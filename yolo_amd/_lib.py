@@ -33,6 +33,7 @@ SIGNATURES = {
     "yolo_conv_benchmark": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "yolo_debug_set_conv_cfg": (_i, [_i]),
     "yolo_upsample2x": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "yolo_upsample_nearest": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "yolo_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "yolo_reorg_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "yolo2_net_create": (_i, [_i, _i, _i, _vp, _sz, _c.POINTER(_vp)]),
@@ -42,7 +43,7 @@ SIGNATURES = {
     "yolo_reorg2x": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "yolo2_decode": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "yolo2_nms_workspace_bytes": (_sz, [_i, _i, _i]),
-    "yolo2_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _c.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "yolo2_nms": (_i, [_vp, _vp, _i, _i, _i, _f, _c.c_double, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "yolo_net_detect_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "yolo_net_detect": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "yolo_preprocess": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),

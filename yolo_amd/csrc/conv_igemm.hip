@@ -1595,6 +1595,7 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         // im2col kernel on 16x16x32 MFMAs with the wave-private (81) / register (88) epilogue (plain and residual layers only)
         case 81: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 0, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
         case 88: if (plain) return launch_cfg<BF16, 128, 128, 4, 2, 2, 16, 3, 1>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 89: if (plain) return launch_cfg<BF16, 192, 128, 4, 2, 2, 16, 3, 2>(k, stream); return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);   // 88 with 48 x 64 waves: 80 KB, two workgroups per CU
         case 96: case 97:                                                   // direct-A 1x1 kernel, 8 / 4 waves per workgroup
             if constexpr (BF16) {
                 if (direct_ok) {

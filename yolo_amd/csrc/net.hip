@@ -601,6 +601,22 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
             res_p = p;
             continue;
         }
+#ifdef YOLO_EXP
+        {
+            static const int skipf = [] { const char* e = getenv("YOLO_SKIP_CLASS"); return e ? atoi(e) : 0; }();
+            if ((skipf & 1024) && fuse_front && st.layer == 1) continue;      // 1024: front kernel
+            if ((skipf & 2048) && fuse_res && st.layer == 3) continue;        // 2048: fused first residual block
+            static const int dblf = [] { const char* e = getenv("YOLO_DOUBLE_CLASS"); return e ? atoi(e) : 0; }();
+            if ((dblf & 1024) && fuse_front && st.layer == 1) { rc = run_front(*net->layers[0], L, front_p, p, (hipStream_t)stream); if (rc != YOLO_OK) return rc; }
+            if ((dblf & 2048) && fuse_res && st.layer == 3) {
+                ConvLaunch q1 = res_p, q3 = p;
+                fill_conv(*net->layers[2], q1);
+                fill_conv(L, q3);
+                rc = launch_res_block(q1, q3, (hipStream_t)stream);
+                if (rc != YOLO_OK) return rc;
+            }
+        }
+#endif
         if (fuse_res && st.layer == 3) {
             ConvLaunch p1 = res_p, p3 = p;
             fill_conv(*net->layers[2], p1);
@@ -622,6 +638,23 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
             }
             continue;
         }
+#ifdef YOLO_EXP
+        {   // experiment builds only: YOLO_SKIP_CLASS=<bit mask> leaves the launches of whole layer classes out (outputs are
+            // garbage; the step time without a class = its marginal cost).  1 s2 3x3, 2 1x1 @13, 4 1x1 @26, 8 1x1 @52, 16 1x1 @104,
+            // 32 heads + scatters + concat 1x1, 64 3x3 @104, 128 3x3 @13, 256 3x3 @26, 512 3x3 @52
+            static const int skip = [] { const char* e = getenv("YOLO_SKIP_CLASS"); return e ? atoi(e) : 0; }();
+            int cls = 0;
+            const bool special = st.out <= -2 || st.upsample || L.cin == 768 || L.cin == 384;
+            if (special) cls = 32;
+            else if (L.k == 3 && L.stride == 2) cls = 1;
+            else if (L.k == 1) cls = p.W <= 16 ? 2 : p.W <= 32 ? 4 : p.W <= 64 ? 8 : 16;
+            else cls = p.W <= 16 ? 128 : p.W <= 32 ? 256 : p.W <= 64 ? 512 : 64;
+            if (skip & cls) continue;
+            // YOLO_DOUBLE_CLASS=<mask>: launch the class twice (same outputs, valid data): step time minus the base = its cost
+            static const int dbl = [] { const char* e = getenv("YOLO_DOUBLE_CLASS"); return e ? atoi(e) : 0; }();
+            if (dbl & cls) { rc = run_conv(L, p, (hipStream_t)stream); if (rc != YOLO_OK) return rc; }
+        }
+#endif
         rc = run_conv(L, p, (hipStream_t)stream);
         if (rc != YOLO_OK) return rc;
         if (record_kernel_names) net->kernel_names[st.layer] = last_kernel_name();

@@ -238,8 +238,9 @@ template <int MODE>
 __device__ __forceinline__ void nms_select_block(const int bc, const float* __restrict__ boxes, int n, int C, int max_boxes,
                                                  float iou_thr, const int* __restrict__ cand_count,
                                                  u64* __restrict__ cand_keys, int* __restrict__ sel_count,
-                                                 int* __restrict__ sel_idx, float* __restrict__ sel_score, f32x4* selbox) {
-    __shared__ u64 skeys[kSortCap];            // 16 KB: the round's keys; before they are gathered, the radix histogram
+                                                 int* __restrict__ sel_idx, float* __restrict__ sel_score, f32x4* selbox,
+                                                 u64* skeys) {
+    // skeys[kSortCap] (16 KB, the kernel's): the round's keys; before they are gathered, the radix histogram
     __shared__ u64 masks[64];
     __shared__ int part[256];
     int* const hist = (int*)skeys;             // 4096 bins = the same 16 KB; never live together with the keys
@@ -407,16 +408,19 @@ __global__ __launch_bounds__(256) void nms_select_kernel(const float* __restrict
                                                          float iou_thr, const int* __restrict__ cand_count,
                                                          u64* __restrict__ cand_keys, int* __restrict__ sel_count,
                                                          int* __restrict__ sel_idx, float* __restrict__ sel_score) {
-    extern __shared__ f32x4 selbox[];          // [max_boxes] selected boxes of the block path (dynamic: a small LDS footprint
-                                               // keeps 8 workgroups per CU)
-    __shared__ u64 wsort[4][64];
-    __shared__ u64 wmask[4][64];
+    extern __shared__ f32x4 selbox[];          // [max_boxes] selected boxes of the block path (dynamic: ~18 KB + 16 max_boxes bytes
+                                               // of LDS per workgroup, 8 workgroups per CU at max_boxes 50)
+    // one 16 KB array for both paths (a workgroup runs exactly one of them): the block path's key buffer; the wave path's
+    // rank rows wsort[4][64] and mask rows wmask[4][64] in its first 4 KB
+    __shared__ u64 skeys[kSortCap];
+    u64 (*const wsort)[64] = (u64 (*)[64])skeys;
+    u64 (*const wmask)[64] = (u64 (*)[64])(skeys + 256);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsmall = (nbc + 3) >> 2;              // workgroups [0, nsmall): four short lists each; [nsmall, nsmall + nbc): one
     if ((int)blockIdx.x >= nsmall) {                // workgroup per list, which leaves at once unless the list is a long one
         const int bc = (int)blockIdx.x - nsmall;
         if (cand_count[bc] > 64)
-            nms_select_block<MODE>(bc, boxes, n, C, max_boxes, iou_thr, cand_count, cand_keys, sel_count, sel_idx, sel_score, selbox);
+            nms_select_block<MODE>(bc, boxes, n, C, max_boxes, iou_thr, cand_count, cand_keys, sel_count, sel_idx, sel_score, selbox, skeys);
         return;
     }
     const int bc0 = blockIdx.x * 4;

@@ -279,7 +279,48 @@ __global__ void upsample2x_kernel(const f32x4* __restrict__ in, f32x4* __restric
     }
 }
 
+// ---- upsample_layer for any output size: tf.image.resize_nearest_neighbor(align_corners=True) as TF 1.x computes it:
+// scale = (in - 1) / (out - 1) (0 when out == 1), src = min(round(dst * scale), in - 1), in float32 with separately rounded
+// multiply and add (oracle/yolo_oracle.py upsample_layer).
+template <typename T>
+__global__ void upsample_nearest_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int CV, int Ho, int Wo,
+                                        float sy, float sx) {
+    const size_t total = (size_t)B * Ho * Wo * CV;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % CV);
+        size_t t = i / CV;
+        const int x = (int)(t % Wo);
+        t /= Wo;
+        const int y = (int)(t % Ho);
+        const size_t b = t / Ho;
+        int iy = (int)floorf(__fadd_rn(__fmul_rn((float)y, sy), 0.5f));
+        int ix = (int)floorf(__fadd_rn(__fmul_rn((float)x, sx), 0.5f));
+        iy = iy < H - 1 ? iy : H - 1;
+        ix = ix < W - 1 ? ix : W - 1;
+        out[i] = in[((b * H + iy) * W + ix) * CV + c];
+    }
+}
+
 }  // namespace yolo
+
+extern "C" int yolo_upsample_nearest(const float* in, int B, int H, int W, int C, int Ho, int Wo, float* out, void* stream) {
+    YOLO_REQUIRE(in && out, YOLO_ERR_ARG, "upsample_nearest: null pointer");
+    YOLO_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, YOLO_ERR_SHAPE, "upsample_nearest: non-positive size");
+    const float sy = Ho > 1 ? (float)((double)(H - 1) / (double)(Ho - 1)) : 0.f;
+    const float sx = Wo > 1 ? (float)((double)(W - 1) / (double)(Wo - 1)) : 0.f;
+    const bool vec = C % 4 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0;
+    const size_t total = (size_t)B * Ho * Wo * (vec ? C / 4 : C);
+    if (vec)
+        hipLaunchKernelGGL(yolo::upsample_nearest_kernel<yolo::f32x4>, dim3(yolo::cast_grid(total, 1)), dim3(256), 0, (hipStream_t)stream,
+                           (const yolo::f32x4*)in, (yolo::f32x4*)out, B, H, W, C / 4, Ho, Wo, sy, sx);
+    else
+        hipLaunchKernelGGL(yolo::upsample_nearest_kernel<float>, dim3(yolo::cast_grid(total, 1)), dim3(256), 0, (hipStream_t)stream,
+                           in, out, B, H, W, C, Ho, Wo, sy, sx);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
 
 extern "C" int yolo_upsample2x(const float* in, int B, int H, int W, int C, float* out, void* stream) {
     YOLO_REQUIRE(in && out, YOLO_ERR_ARG, "upsample2x: null pointer");

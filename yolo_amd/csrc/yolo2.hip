@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void nms2_kernel(const double* __restrict__ bo
                                                    int n, int C, float thr, double iou_thr, int max_det,
                                                    u64* __restrict__ keys_ws, int* __restrict__ out_count,
                                                    int* __restrict__ out_cls, double* __restrict__ out_boxes,
-                                                   float* __restrict__ out_probs, int* __restrict__ out_flat) {
+                                                   float* __restrict__ out_probs, int* __restrict__ out_flat,
+                                                   int* __restrict__ out_truncated) {
     __shared__ int s_count;
     __shared__ u64 wbest[4];
     __shared__ u64 bcast;
@@ -132,8 +133,12 @@ __global__ __launch_bounds__(256) void nms2_kernel(const double* __restrict__ bo
         ++ndet;
     }
     // degenerate boxes (w*h == 0, inf, NaN: IoU is NaN, never > thr) let several classes of ONE box survive, so n rows are
-    // not a bound; the reference (Detector.py:72-83) has no cap: a count of max_det + 1 tells the caller rows were cut
-    if (tid == 0) out_count[b] = truncated ? max_det + 1 : ndet;
+    // not a bound; the reference (Detector.py:72-83) has no cap.  The count never exceeds the rows written; that rows were cut
+    // is reported through out_truncated
+    if (tid == 0) {
+        out_count[b] = ndet;
+        if (out_truncated) out_truncated[b] = truncated ? 1 : 0;
+    }
 }
 
 }  // namespace yolo
@@ -165,12 +170,12 @@ extern "C" size_t yolo2_nms_workspace_bytes(int B, int n, int C) {
 // of the box with prob >= threshold, :67), box (cx,cy,w,h) f64, prob f32, flat candidate index box*C+c.
 extern "C" int yolo2_nms(const double* boxes, const float* probs, int B, int n, int C, float threshold, double iou_thresh,
                          int max_det, int32_t* out_counts, int32_t* out_cls, double* out_boxes, float* out_probs,
-                         int32_t* out_flat, void* workspace, size_t workspace_bytes, void* stream) {
+                         int32_t* out_flat, int32_t* out_truncated, void* workspace, size_t workspace_bytes, void* stream) {
     YOLO_REQUIRE(boxes && probs && out_counts && out_cls && out_boxes && out_probs && workspace, YOLO_ERR_ARG, "yolo2_nms: null pointer");
     YOLO_REQUIRE(B > 0 && n > 0 && C > 0 && max_det > 0 && (long long)n * C < (1ll << 31), YOLO_ERR_ARG, "yolo2_nms: bad sizes");
     YOLO_REQUIRE(workspace_bytes >= yolo2_nms_workspace_bytes(B, n, C), YOLO_ERR_WORKSPACE, "yolo2_nms: workspace too small");
     hipLaunchKernelGGL(nms2_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, boxes, probs, n, C, threshold, iou_thresh,
-                       max_det, (u64*)workspace, out_counts, out_cls, out_boxes, out_probs, out_flat);
+                       max_det, (u64*)workspace, out_counts, out_cls, out_boxes, out_probs, out_flat, out_truncated);
     YOLO_HIP_CHECK(hipGetLastError());
     return YOLO_OK;
 }

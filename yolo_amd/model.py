@@ -156,6 +156,11 @@ class yolov3(object):
         if anc.shape != (9, 2):
             raise ValueError("detect needs 9 anchors, got %s" % (anc.shape,))
         L = _lib.lib()
+        if C > 250:
+            # the fused post-processing keeps one box's class scores in an LDS tile (<= 250 classes); the reference has no such
+            # limit (nms_utils.py:7), so wider heads take the reference's own sequence of calls on the GPU: forward -> predict
+            # -> conf*prob -> per-image gpu_nms (same results, the [N, n, C] score tensor exists)
+            return self.detect_unfused(x, max_boxes, score_thresh, iou_thresh)
         need = L.yolo_net_detect_workspace_bytes(self._net, B, H, W, int(max_boxes))
         if need == 0:
             raise ValueError("detect: bad sizes B=%d H=%d W=%d C=%d max_boxes=%d (H, W must be multiples of 32)"

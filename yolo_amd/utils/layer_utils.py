@@ -121,13 +121,18 @@ def yolo_block(inputs, filters):
 
 
 def upsample_layer(inputs, out_shape):
-    """layer_utils.py:67-72.  Only the exact-2x case of the network is implemented: for it
-    resize_nearest_neighbor(align_corners=True) equals src = dst // 2 (SURVEY.md B.3)."""
+    """layer_utils.py:67-72: tf.image.resize_nearest_neighbor(inputs, (out_shape[1], out_shape[2]), align_corners=True).
+    The exact-2x case of the network (where the TF rule equals src = dst // 2, SURVEY.md B.3) runs the 16-byte-per-lane
+    kernel; any other size the general one (TF 1.x rounding: src = min(round(dst * (in - 1) / (out - 1)), in - 1))."""
     x = _tensor.as_dev_f32(inputs)
     B, H, W, C = [int(v) for v in x.shape]
-    new_height, new_width = out_shape[1], out_shape[2]
-    if new_height != 2 * H or new_width != 2 * W:
-        raise ValueError("upsample_layer: only exact 2x is implemented (%dx%d -> %dx%d)" % (H, W, new_height, new_width))
-    out = _tensor.empty((B, 2 * H, 2 * W, C))
-    _lib.check(_lib.lib().yolo_upsample2x(x.data_ptr(), B, H, W, C, out.data_ptr(), _tensor.stream_ptr()))
+    new_height, new_width = int(out_shape[1]), int(out_shape[2])
+    if new_height <= 0 or new_width <= 0:
+        raise ValueError("upsample_layer: bad output size %dx%d" % (new_height, new_width))
+    out = _tensor.empty((B, new_height, new_width, C))
+    if new_height == 2 * H and new_width == 2 * W and C % 4 == 0:
+        _lib.check(_lib.lib().yolo_upsample2x(x.data_ptr(), B, H, W, C, out.data_ptr(), _tensor.stream_ptr()))
+    else:
+        _lib.check(_lib.lib().yolo_upsample_nearest(x.data_ptr(), B, H, W, C, new_height, new_width, out.data_ptr(),
+                                                    _tensor.stream_ptr()))
     return out

@@ -76,29 +76,37 @@ class Detector(object):
     def nms(self, boxes, probs, max_det=None):
         """Class-agnostic greedy NMS of Detector.py:63-83 per image on decoded tensors.
         -> (counts int32 [B], class ids int32 [B,max_det], boxes f64 [B,max_det,4], probs f32 [B,max_det],
-        flat candidate index int32 [B,max_det])."""
+        flat candidate index int32 [B,max_det]); counts[i] <= max_det rows of image i are valid.
+        Normally at most one candidate per box survives (same box -> IoU 1 > 0.5), so the default of n rows suffices.
+        Degenerate boxes (zero area, inf / NaN from an exp overflow) have IoU NaN with themselves, so several classes of one
+        box can survive as they do in the reference (Detector.py:72-83, no cap): with the default max_det the call is then
+        repeated with n * C rows, which always suffice; with an explicit max_det the lists are cut there and
+        `self.last_truncated` (bool tensor [B]) says for which images."""
         S, NB, C = self.cell_size, self.box_per_cell, self.num_classes
         n = S * S * NB
         bx = boxes if isinstance(boxes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(boxes, np.float64))
         bx = bx.to(device=_tensor.device(), dtype=torch.float64).contiguous().reshape(-1, n, 4)
         pr = _tensor.as_dev_f32(probs).reshape(-1, n, C)
         B = int(pr.shape[0])
-        # normally at most one survivor per box (same box -> IoU 1 > 0.5): n rows.  Degenerate boxes (zero area, inf / NaN
-        # from an exp overflow) have IoU NaN with themselves, so several classes of one box can survive as they do in the
-        # reference (Detector.py:72-83, no cap): counts[i] == max_det + 1 reports that rows were cut (calc_output_batched
-        # then repeats the call with n * C rows, which always suffice)
-        max_det = int(max_det or n)
         L = _lib.lib()
-        counts = _tensor.empty((B,), torch.int32)
-        cls = _tensor.empty((B, max_det), torch.int32)
-        ob = _tensor.empty((B, max_det, 4), torch.float64)
-        op = _tensor.empty((B, max_det))
-        flat = _tensor.empty((B, max_det), torch.int32)
         ws = _tensor.workspace(L.yolo2_nms_workspace_bytes(B, n, C))
-        _lib.check(L.yolo2_nms(bx.data_ptr(), pr.data_ptr(), B, n, C, self.threshold, self.iou_threshold, max_det,
-                               counts.data_ptr(), cls.data_ptr(), ob.data_ptr(), op.data_ptr(), flat.data_ptr(),
-                               ws.data_ptr(), ws.numel(), _tensor.stream_ptr()))
-        return counts, cls, ob, op, flat
+
+        def run(rows):
+            counts = _tensor.empty((B,), torch.int32)
+            trunc = _tensor.empty((B,), torch.int32)
+            cls = _tensor.empty((B, rows), torch.int32)
+            ob = _tensor.empty((B, rows, 4), torch.float64)
+            op = _tensor.empty((B, rows))
+            flat = _tensor.empty((B, rows), torch.int32)
+            _lib.check(L.yolo2_nms(bx.data_ptr(), pr.data_ptr(), B, n, C, self.threshold, self.iou_threshold, rows,
+                                   counts.data_ptr(), cls.data_ptr(), ob.data_ptr(), op.data_ptr(), flat.data_ptr(),
+                                   trunc.data_ptr(), ws.data_ptr(), ws.numel(), _tensor.stream_ptr()))
+            return (counts, cls, ob, op, flat), trunc
+        out, trunc = run(int(max_det or n))
+        if max_det is None and bool(trunc.any().item()):
+            out, trunc = run(n * C)
+        self.last_truncated = trunc != 0
+        return out
 
     def calc_output(self, output):
         """ONE image's logits (any shape with 13*13*125 values) -> [[class_name, cx, cy, w, h, prob], ...]."""
@@ -109,9 +117,7 @@ class Detector(object):
     def calc_output_batched(self, output):
         """Per-image calc_output for a batch of logits -> list (per image) of result lists."""
         boxes, probs = self.decode(output)
-        counts, cls, ob, op, _ = self.nms(boxes, probs)
-        if int(counts.max().item()) > int(cls.shape[1]):                          # truncated: the reference has no cap
-            counts, cls, ob, op, _ = self.nms(boxes, probs, self.cell_size * self.cell_size * self.box_per_cell * self.num_classes)
+        counts, cls, ob, op, _ = self.nms(boxes, probs)                           # repeats itself with n * C rows when n do not suffice
         counts, cls, ob, op = counts.cpu().numpy(), cls.cpu().numpy(), ob.cpu().numpy(), op.cpu().numpy()
         out = []
         for b in range(len(counts)):
