@@ -281,7 +281,7 @@ __global__ void upsample2x_kernel(const f32x4* __restrict__ in, f32x4* __restric
 
 // ---- upsample_layer for any output size: tf.image.resize_nearest_neighbor(align_corners=True) as TF 1.x computes it:
 // scale = (in - 1) / (out - 1) (0 when out == 1), src = min(round(dst * scale), in - 1), in float32 with separately rounded
-// multiply and add (oracle/yolo_oracle.py upsample_layer).
+// multiply and add.
 template <typename T>
 __global__ void upsample_nearest_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int CV, int Ho, int Wo,
                                         float sy, float sx) {
