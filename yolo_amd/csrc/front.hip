@@ -26,9 +26,12 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
+// image patch (bf16) | stem patch (the output staging of a tile reuses its first TH * 16 * 144 bytes) | stride-2 weights | biases
 template <int TH>
-constexpr int front_lds_bytes() { return (2 * TH + 3) * 108 * 4 + 8 * (2 * TH + 1) * 17 * 16 + 64 * 592 + TH * 16 * 144; }
+constexpr int front_lds_bytes() { return (((2 * TH + 3) * 108 * 2 + 15) & ~15) + 8 * (2 * TH + 1) * 17 * 16 + 64 * 592 + 96 * 4; }
 
 struct FrontK {
     const float* img;      // [B,H,W,3] f32
@@ -49,11 +52,11 @@ __device__ __forceinline__ float act(float v) {
 }
 
 template <int TH, int ACT>
-__global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
+__global__ __launch_bounds__(64 * TH, TH == 8 ? 4 : 1) void front_kernel(FrontK p) {
     constexpr int NT = 64 * TH, NW = TH;
     constexpr int SH = 2 * TH + 1, SWH = 17;           // stem patch: SH x 33 pixels, x stored as (parity, x/2)
     constexpr int IH = SH + 2, IROW = 105, IWP = 108;  // image patch: IH x 35 pixels x 3 floats, rows padded to 108
-    constexpr int IMG_BYTES = IH * IWP * 4;
+    constexpr int IMG_BYTES = (IH * IWP * 2 + 15) & ~15;
     constexpr int PLANE = SH * SWH * 16;               // one (chunk, parity) plane of the stem patch
     constexpr int STEM_BYTES = 8 * PLANE;
     constexpr int W1_ROW = 592, W1_BYTES = 64 * W1_ROW;
@@ -61,12 +64,14 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
     constexpr int NE = (IH * IROW + NT - 1) / NT;      // image floats per thread
     constexpr int NG = SH + 1;                         // stem groups of 32 pixels: SH rows of x = 0..31, one of x = 32
 
-    static_assert(IMG_BYTES % 16 == 0 && (IMG_BYTES + STEM_BYTES + W1_BYTES + ST_BYTES) <= 160 * 1024, "LDS budget");
+    static_assert(IMG_BYTES % 16 == 0 && ST_BYTES <= STEM_BYTES && front_lds_bytes<TH>() == IMG_BYTES + STEM_BYTES + W1_BYTES + 384 &&
+                  front_lds_bytes<TH>() <= 80 * 1024, "LDS budget: two workgroups per CU");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    float* const img = (float*)lds;
+    unsigned short* const img = (unsigned short*)lds;       // bf16: rounded once when the patch lands, not per gathered tap
     char* const stem = lds + IMG_BYTES;
     char* const w1s = stem + STEM_BYTES;
-    char* const stage = w1s + W1_BYTES;
+    float* const bias = (float*)(w1s + W1_BYTES);           // [32] stem, [64] stride-2 conv
+    char* const stage = stem;                               // the stem patch is dead once the tile's MFMAs have read it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,14 +86,13 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
     }
     const bf16x8 wf0 = __builtin_bit_cast(bf16x8, p.w0[fr * 4 + fh]);        // A[row = cout fr][k = 8 fh + j]
     const bf16x8 wf1 = __builtin_bit_cast(bf16x8, p.w0[fr * 4 + 2 + fh]);    //                  k = 16 + 8 fh + j
-    float b0v[16], b1v[16];
+    if (tid < 32) bias[tid] = p.b0[tid];
+    else if (tid < 96) bias[tid] = p.b1[tid - 32];
     const int wm = wave >> 1, wn = wave & 1;           // conv phase: wave tile = 32 pixels (2 tile rows) x 32 channels
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ch = (r & 3) + 8 * (r >> 2) + 4 * fh;
-        b0v[r] = p.b0[ch];
-        b1v[r] = p.b1[wn * 32 + ch];
-    }
+    // accumulator register 4 q + i of a lane is channel 8 q + 4 fh + i: its biases are four consecutive floats per q, read from
+    // LDS where they are used (keeping 32 of them in registers cost the second workgroup per CU)
+    const f32x4* const b0p = (const f32x4*)(bias + 4 * fh);
+    const f32x4* const b1p = (const f32x4*)(bias + 32 + wn * 32 + 4 * fh);
     // stem gather tables: this lane's 16 im2col taps k = 16 m + 8 fh + j as float offsets inside the image patch
     int koff[2][8];
 #pragma unroll
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
                 const int gy = gy0 + (ipos[e] & 255), gx = gx0 + ((ipos[e] >> 8) & 255);
                 inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             }
-            if (lidx[e] >= 0) img[lidx[e]] = inside ? pre[e] : 0.f;
+            if (lidx[e] >= 0) img[lidx[e]] = __builtin_bit_cast(unsigned short, (__bf16)(inside ? pre[e] : 0.f));
         }
     };
 
@@ -179,19 +183,14 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
             const bool pv = g < SH || fr < SH;
             const int sy = g < SH ? g : (pv ? fr : 0);       // lanes past the column group read row 0, unused
             const int sx = g < SH ? fr : 32;
-            const float* base = img + sy * IWP + sx * 3;
-            float gv[2][8];
+            const unsigned short* base = img + sy * IWP + sx * 3;
+            u16x8 g0, g1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                gv[0][j] = base[koff[0][j]];
-                gv[1][j] = base[koff[1][j]];
+                g0[j] = base[koff[0][j]];
+                g1[j] = base[koff[1][j]];
             }
-            bf16x8 a0, a1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                a0[j] = (__bf16)gv[0][j];
-                a1[j] = (__bf16)gv[1][j];
-            }
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, g0), a1 = __builtin_bit_cast(bf16x8, g1);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -203,9 +202,10 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
                 char* dst = stem + (((sx & 1) * SH + sy) * SWH + (sx >> 1)) * 16 + fh * 8;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {          // channels 8q + 4fh .. +3 -> chunk q, bytes fh*8..
+                    const f32x4 bq = b0p[2 * q];
                     bf16x4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(outside ? 0.f : act<ACT>(acc[4 * q + i] + b0v[4 * q + i]));
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(outside ? 0.f : act<ACT>(acc[4 * q + i] + bq[i]));
                     *(bf16x4*)(dst + q * 2 * PLANE) = o;
                 }
             }
@@ -239,17 +239,21 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
                 for (int hh = 0; hh < 2; ++hh)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][hh], bfr[t & 1][hh], acc, 0, 0, 0);
             }
-            // bias + leaky -> staging [pixel][64 ch] bf16 (row stride 144 B)
-            char* dst = stage + (wm * 32 + fr) * ST_ROW + (wn * 32 + 4 * fh) * 2;
+            // bias + leaky -> staging [pixel][64 ch] bf16 (row stride 144 B) in the stem patch's place: every wave has read its
+            // last stem fragment before anybody overwrites it
+            bf16x4 o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bf16x4 o;
+                const f32x4 bq = b1p[2 * q];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)act<ACT>(acc[4 * q + i] + b1v[4 * q + i]);
-                *(bf16x4*)(dst + q * 16) = o;
+                for (int i = 0; i < 4; ++i) o[q][i] = (__bf16)act<ACT>(acc[4 * q + i] + bq[i]);
             }
+            __syncthreads();
+            char* dst = stage + (wm * 32 + fr) * ST_ROW + (wn * 32 + 4 * fh) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(bf16x4*)(dst + q * 16) = o[q];
         }
-        __syncthreads();                               // staging complete; img and stem patch are free again
+        __syncthreads();                               // staging complete; the image patch is free again
 
         if (next < p.ntiles) store_image_patch(noy0, nox0);
         // ---- stores: 8 x 16 B per pixel, pixels of a tile row contiguous in memory ----------------------------
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(64 * TH) void front_kernel(FrontK p) {
             const u32x4 v = *(const u32x4*)(stage + pix * ST_ROW + ch * 16);
             *(u32x4*)(p.out + ((((long long)b * Ho + oy0 + py) * Wo + ox0 + pxx) * p.out_ld + p.out_coff) * 2 + ch * 16) = v;
         }
-        __syncthreads();                               // next image patch visible; staging free
+        __syncthreads();                               // next image patch visible; staging (= stem patch) free
     }
 }
 
@@ -305,7 +309,7 @@ int launch_front(const ConvLaunch& c0, const ConvLaunch& c1, hipStream_t stream)
     k.ntiles = (int)nt;
     // persistent workgroups: as many as fit a CU's LDS (TH = 8: one of 8 waves, TH = 4: two of 4 waves), each walks
     // ntiles / grid tiles
-    int grid = 256 * (bpc_env > 0 ? bpc_env : (th == 4 ? 2 : 1));
+    int grid = 256 * (bpc_env > 0 ? bpc_env : 2);
     if (grid > k.ntiles) grid = k.ntiles;
     return th == 4 ? launch_front_th<4>(k, grid, c0.leaky, stream) : launch_front_th<8>(k, grid, c0.leaky, stream);
 }
