@@ -1573,10 +1573,11 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         // 16-wave 256x128 workgroup at 52x52, 7 % at 104x104)
         else if (halo_ok && (int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 80 * 1024) cfg = BF16 ? 69 : 28;
         else if (halo_ok && patch_bufs * prows256 * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) cfg = 26;
-        // plain bf16 1x1 layers on maps of 26 x 26 and larger: activations straight into MFMA operand registers (round 3: 104x104
-        // 65 -> 54 us, 52x52 37 -> 35, 26x26 30 -> 27; bit-identical to 88).  13x13 (K = 1024, four channel tiles re-read every
-        // pixel row) stays on the im2col kernel (25 vs 28 us).
-        else if (direct_ok && k.W > 16) cfg = 97;
+        // plain bf16 1x1 layers: activations straight into MFMA operand registers (round 3: 104x104 65 -> 54 us, 52x52 37 -> 35,
+        // 26x26 30 -> 27 per launch on cold inputs; bit-identical to 88).  At 13x13 (K = 1024, four channel tiles re-read every
+        // pixel row) a launch on cold inputs is slower (28 vs 25 us) but the step is 0.5 - 1 % faster (three interleaved A/B runs
+        // of 100 steps): in the network the rows come from L2 / MALL and the small LDS footprint lets other lanes' kernels share the CU.
+        else if (direct_ok) cfg = 97;
         else cfg = (BF16 && plain) ? 88 : 5;   // 88: 5 on 16x16x32 MFMAs with the register epilogue (+8 % on the 1x1 layers)
     }
     switch (cfg) {
