@@ -362,6 +362,21 @@ def main():
                             "what": "same step with the conv stack on exact-f32 MFMAs (v_mfma_f32_32x32x2_f32): the parity path"}
             del net32
 
+    # ---- latency at batch 1 (the reference's own published figure is a batch-1 latency): default plan vs the opt-in
+    # split-K small-batch plan (yolo_net_set_small_batch_plan), same detect call, events on the launch stream
+    if not args.no_extras and world == 1 and args.dtype == "bf16":
+        one = images[:1].contiguous()
+        net_sb = yolov3(80, DEFAULT_ANCHORS, dtype="bf16", small_batch_plan=True).load_weight_stream(stream)
+        d_ms = event_ms(lambda: net.detect(one, 50, 0.5, 0.5), reps=100, warm=10)
+        s_ms = event_ms(lambda: net_sb.detect(one, 50, 0.5, 0.5), reps=100, warm=10)
+        sf_ms = event_ms(lambda: net_sb.forward(one), reps=100, warm=10)
+        side["small_batch"] = {"batch": 1, "default_plan_ms": round(d_ms, 4), "small_batch_plan_ms": round(s_ms, 4),
+                               "small_batch_plan_forward_ms": round(sf_ms, 4), "images_per_sec": round(1e3 / s_ms, 1),
+                               "what": "one %dx%d image per detect call, 100 calls back to back; small_batch_plan: launches with fewer than "
+                                       "128 tiles split their K loop over up to 512 workgroups (f32 partial tiles + an ordered reduce launch); "
+                                       "opt-in per handle, results within the bf16 tolerance of the default plan, not bit-identical" % (S, S)}
+        del net_sb
+
     h2d = None
     if args.h2d:
         from yolo_amd.preprocess import preprocess

@@ -1,4 +1,4 @@
-"""Per-layer times of one forward at small batch (python scripts/b1_layers.py [B])."""
+"""Per-layer times of one forward at small batch (python scripts/b1_layers.py [B] [split])."""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,7 +6,7 @@ from yolo_amd.model import yolov3
 from yolo_amd.utils.misc_utils import DEFAULT_ANCHORS
 from yolo_amd.weights import synth_darknet_stream
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-net = yolov3(80, DEFAULT_ANCHORS, dtype="bf16").load_weight_stream(synth_darknet_stream(80, seed=1234))
+net = yolov3(80, DEFAULT_ANCHORS, dtype="bf16", small_batch_plan=len(sys.argv) > 2).load_weight_stream(synth_darknet_stream(80, seed=1234))
 x = torch.rand(B, 416, 416, 3, device="cuda")
 acc = None
 for _ in range(6):

@@ -22,6 +22,7 @@ SIGNATURES = {
     "yolo_net_destroy": (_i, [_vp]),
     "yolo_net_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "yolo_net_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "yolo_net_set_small_batch_plan": (_i, [_vp, _i]),
     "yolo_net_num_layers": (_i, [_vp]),
     "yolo_net_layer_info": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "yolo_net_layer_kernel": (_c.c_char_p, [_vp, _i]),

@@ -54,6 +54,11 @@ struct ConvLaunch {
     int upsample;          // 1: write every output pixel to the 2x2 block of a [B,2Ho,2Wo] tensor
     int out_f32;           // 1: out is float32 regardless of dtype (detection heads), scalar stores
     int reorg;             // 1: space-to-depth scatter (yolo_v2.py:97-113): pixel (y,x) -> (y/2,x/2), channel block (y&1)*2+(x&1)
+    // small-batch plan (yolo_net_set_small_batch_plan): the K loop of a layer whose grid would leave most CUs idle is cut into
+    // `S` slices run by S times as many workgroups; f32 partial tiles go to `scratch` and a second launch adds them in slice order
+    int small_plan;        // 1: the launcher may split K
+    void* scratch;         // >= S * M * Cout * 4 bytes when small_plan
+    size_t scratch_bytes;
 };
 
 // Measurement aid: when `record_kernel_names` is set (only yolo_net_forward_timed sets it), every launcher

@@ -54,6 +54,9 @@ struct ConvK {
     int kpad_bytes, nsteps;
     int leaky, upsample, out_f32, reorg;
     int M, ntm, ntn;
+    int splitk;            // > 1: blockIdx.y = K slice; raw f32 accumulators go to partial[slice][M][Cout], no epilogue
+    float* partial;
+    long long partial_cap; // floats the scratch area holds (host side only)
 };
 
 #define GLDS16(gptr, ldsptr)                                                                   \
@@ -199,6 +202,87 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, AccT (&acc)[TM][TN
         }
     }
     }   // pass
+}
+
+// counted wait: at most N vector-memory loads (register or LDS-DMA) still pending; loads complete in issue order
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// ---- split-K (small-batch plan): raw f32 accumulators -> partial[slice][M][Cout]; splitk_reduce_kernel finishes the layer ----
+// D[pixel][channel] accumulators (fr = lane % MS channel column, fh = lane / MS; register r = pixel row (r&3) + 8*(r>>2) + 4*fh)
+template <int TM, int TN, int MS, typename AccT>
+__device__ __forceinline__ void store_partial_rows(const ConvK& p, AccT (&acc)[TM][TN], int slice, int m0, int n0, int wm0, int wn0, int fr, int fh) {
+    float* const base = p.partial + (long long)slice * p.M * p.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < MS * MS / 64; ++r) {
+            const int m = m0 + wm0 + i * MS + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * MS + fr;
+                if (n < p.Cout) base[(long long)m * p.Cout + n] = acc[i][j][r];
+            }
+        }
+}
+// D[channel][pixel] accumulators of the 16x16x32 MFMAs with swapped operands: a lane holds channels 16 j + 4 fq + 0..3 of pixel 16 i + fr
+template <int TM, int TN>
+__device__ __forceinline__ void store_partial_cols(const ConvK& p, f32x4 (&acc)[TM][TN], int slice, int m0, int n0, int wm0, int wn0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    float* const base = p.partial + (long long)slice * p.M * p.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + 16 * i + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + 16 * j + 4 * fq;
+            if (n < p.Cout) *(f32x4*)(base + (long long)m * p.Cout + n) = acc[i][j];      // Cout % 8 == 0 on this path
+        }
+    }
+}
+// out = bf16(act(sum over slices in slice order + bias) + residual): one thread per (pixel, 8 channels), the arithmetic of the
+// epilogues above on the summed accumulator
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK p) {
+    const int CH = p.Cout >> 3;
+    const long long total = (long long)p.M * CH;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int m = (int)(idx / CH), n = (int)(idx - (long long)m * CH) * 8;
+    const long long slice = (long long)p.M * p.Cout;
+    const float* src = p.partial + (long long)m * p.Cout + n;
+    f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+    for (int s = 1; s < p.splitk; ++s) {
+        const f32x4 b0 = *(const f32x4*)(src + s * slice), b1 = *(const f32x4*)(src + s * slice + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] += b0[e]; a1[e] += b1[e]; }
+    }
+    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] += p.bias[n + e];
+        if (p.leaky == 1) v[e] = leaky_v3(v[e]);
+        else if (p.leaky == 2) v[e] = __builtin_fmaxf(0.1f * v[e], v[e]);
+    }
+    if (p.res) {
+        const bf16x8 rv = *(const bf16x8*)(p.res + ((long long)m * p.res_ld + p.res_coff + n) * 2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    *(bf16x8*)(p.out + ((long long)m * p.out_ld + p.out_coff + n) * 2) = o;
+}
+static int launch_splitk_reduce(const ConvK& k, hipStream_t stream) {
+    const long long total = (long long)k.M * (k.Cout >> 3);
+    note_kernel("yolo::splitk_reduce_kernel");
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, k);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
 }
 
 // ---- register epilogue (bf16, 16x16x32 MFMAs with the operands swapped: D[channel][pixel]) --------------------------------
@@ -458,10 +542,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
         a_off[i] = off;
         a_mask[i] = mask;
     }
+    // K slice of this workgroup (split-K: blockIdx.y; otherwise the whole K)
+    const int nsl = p.splitk > 1 ? (p.nsteps + p.splitk - 1) / p.splitk : p.nsteps;
+    const int s_begin = p.splitk > 1 ? (int)blockIdx.y * nsl : 0;
+    const int s_end = s_begin + nsl < p.nsteps ? s_begin + nsl : p.nsteps;
     int tap = 0;
-    int cib = chunk * 16;
+    int cib = chunk * 16 + s_begin * 128;
     while (cib >= CinB) { cib -= CinB; ++tap; }
-    const char* wsrc = p.w + (long long)(n0 + 8 * wave + (lane >> 3)) * p.kpad_bytes + chunk * 16;
+    const char* wsrc = p.w + (long long)(n0 + 8 * wave + (lane >> 3)) * p.kpad_bytes + chunk * 16 + s_begin * 128;
     const long long w_step = (long long)(8 * NW) * p.kpad_bytes;
     const int in_cb = p.in_coff * SZ;
     const int pix_b = p.in_ld * SZ;
@@ -529,13 +617,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
     const unsigned long long tbeg_ = __builtin_amdgcn_s_memtime();
     unsigned long long tl_ = tbeg_;
 #endif
+    const int nsteps = s_end - s_begin;
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st)
-        if (st < p.nsteps) stage(st);
+        if (st < nsteps) stage(st);
     int cur = 0;
     STAMP(0);                          // prologue: address set-up + first stage issue
-    for (int s = 0; s < p.nsteps; ++s) {
-        if (STAGES == 3 && s + 1 < p.nsteps) {
+    for (int s = 0; s < nsteps; ++s) {
+        if (STAGES == 3 && s + 1 < nsteps) {
             if constexpr (LPS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if constexpr (LPS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if constexpr (LPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -551,7 +640,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         STAMP(2);                      // barrier
-        if (s + STAGES - 1 < p.nsteps) {
+        if (s + STAGES - 1 < nsteps) {
             int nb = cur + STAGES - 1;
             if (nb >= STAGES) nb -= STAGES;
             stage(nb);
@@ -599,6 +688,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv_igemm_kerne
         asm volatile("s_nop 0" :: "v"(acc[0][0][0]));
         STAMP(4);                      // fragment reads + MFMA issue
 #endif
+    }
+    if (p.splitk > 1) {                // uniform: raw partial tile, the reduce launch finishes the layer
+        if constexpr (EPASS == 3 && MS == 16) store_partial_cols<TM, TN>(p, acc, blockIdx.y, m0, n0, wm0, wn0, lane);
+        else store_partial_rows<TM, TN, MS, AccT>(p, acc, blockIdx.y, m0, n0, wm0, wn0, fr, fh);
+        return;
     }
 #if defined(YOLO_EXP) && YOLO_EXP == 6          // EXP 6: im2col kernel without epilogue
     {
@@ -681,9 +775,13 @@ __device__ __forceinline__ int lds_swz(int row) { return MS == 16 ? ((row >> 1) 
 // MS = 16 (bf16 only): the same wave tile out of v_mfma_f32_16x16x32_bf16 - same LDS reads and MFMA cycles per FLOP;
 // the chip holds a higher clock on that shape (MI355X_MICROARCH.md, DVFS give-back item 7).
 // EPASS: epilogue staging passes (conv_epilogue); MINW: waves per SIMD the register allocation must allow.
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB, int MS, int EPASS = 1, int MINW = 1>
+// WB: weight-tile buffers.  2 = one tile of lookahead behind a full wait (the throughput plan: LDS for two workgroups per
+// CU).  > 2 (small-batch plan, one short K slice per workgroup, LDS to spare) = WB - 1 tiles in flight behind a COUNTED
+// wait (XP build only: measured at batch 1, a 9-step slice takes 15 us with WB = 2, 4 or 6).
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB, int MS, int EPASS = 1, int MINW = 1, int WB = 2>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_kernel(ConvK p, int prows) {
     static_assert(MS == 32 || (MS == 16 && BF16), "MFMA shape");
+    static_assert(WB == 2 || (SPB && WB <= 8), "deep weight ring: single patch buffer only (no patch loads between the counted weight loads)");
     static_assert(BM % (WARPS_M * MS) == 0 && BN % (WARPS_N * MS) == 0, "wave tiles must be whole MFMA tiles");
     constexpr int SZ = BF16 ? 2 : 4;
     constexpr int NW = WARPS_M * WARPS_N;
@@ -720,7 +818,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
     const int patch_bytes = prows * 128;          // prows: BM + 2W + 2 rounded up to 8
     char* const patch0 = lds;
     char* const bbuf0 = lds + ((nchunks > 1 && !SPB) ? 2 : 1) * patch_bytes;   // one patch buffer suffices for one chunk
-    char* const zrow = bbuf0 + 2 * B_BYTES;       // 128 zero bytes: source of out-of-image taps
+    char* const zrow = bbuf0 + WB * B_BYTES;      // 128 zero bytes: source of out-of-image taps
     if (tid < 32) ((unsigned*)zrow)[tid] = 0u;    // ordered before the first fragment read by the loop's barrier
 
     // ---- loader state ----------------------------------------------------------------------------
@@ -798,18 +896,33 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
     const unsigned long long rbeg_ = __builtin_amdgcn_s_memrealtime();   // 100 MHz: in-kernel clock = cycles / ticks x 100 MHz
     unsigned long long tl_ = tbeg_;
 #endif
-    // ---- prologue: whole patch of chunk 0 + weight tile (0,0) ----------------------------------------
-    for (int sl = 0; sl < slots; ++sl) load_patch_piece(0, sl);
-    load_b(0, 0, 0);
+    // channel chunks of this workgroup (split-K: blockIdx.y takes nchunks / splitk of them; otherwise all)
+    const int cper = p.splitk > 1 ? nchunks / p.splitk : nchunks;
+    const int c_begin = p.splitk > 1 ? (int)blockIdx.y * cper : 0;
+    const int c_end = c_begin + cper;
+    // ---- prologue: whole patch of the first chunk + its first weight tile ----------------------------
+    for (int sl = 0; sl < slots; ++sl) load_patch_piece(c_begin, sl);
+    load_b(c_begin, 0, 0);
+    // deep weight ring: the tiles of steps 1 .. WB-2 as well; (lc, lt) = the next tile to request, `ahead` = requested tiles
+    // beyond the current step's
+    int lc = c_begin, lt = 1, ahead = 0;
+    if constexpr (WB > 2) {
+        const int total = (c_end - c_begin) * 9;
+        for (int u = 1; u < WB - 1 && u < total; ++u) {
+            load_b(lc, lt, u);
+            if (++lt == 9) { lt = 0; ++lc; }
+            ++ahead;
+        }
+    }
 
     // ---- main loop over (chunk c, tap t); one barrier per step ----------------------------------------
     // Loads issued during step s (next weight tile, 1/9 of the next chunk's patch) must have landed by
     // the barrier that opens step s+1; the buffers they overwrite were last read in step s-1.
     int bcur = 0;
     STAMP(0);
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
         const char* patch = patch0 + (SPB ? 0 : (c & 1) * patch_bytes);
-        if (SPB && c > 0) {                    // every wave is done with chunk c-1: refill the single patch buffer
+        if (SPB && c > c_begin) {              // every wave is done with chunk c-1: refill the single patch buffer
             __builtin_amdgcn_s_barrier();
 #if !defined(YOLO_EXP) || YOLO_EXP != 1         // EXP 1: no refill (stale patch): what the exposed refills cost
             for (int sl = 0; sl < slots; ++sl) load_patch_piece(c, sl);
@@ -817,17 +930,34 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
         }
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (WB > 2) {
+                // loads complete in order: with WB-2 younger tiles requested the current one has landed once at most
+                // (WB-2) * BI loads are pending.  A patch refill (first step of a later chunk) is younger than all of them.
+                if (ahead == WB - 2 && !(t == 0 && c > c_begin)) wait_vmcnt<(WB - 2) * BI>();
+                else wait_vmcnt<0>();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             STAMP(1);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             STAMP(2);
             // prefetch
 #if !defined(YOLO_EXP) || YOLO_EXP != 2         // EXP 2: no weight loads in the loop (stale weights)
-            if (t < 8) load_b(c, t + 1, bcur ^ 1);
-            else if (c + 1 < nchunks) load_b(c + 1, 0, bcur ^ 1);
+            if constexpr (WB > 2) {
+                // the buffer read in the previous step (free since this step's barrier) takes the tile WB-1 steps ahead
+                if (lc < c_end) {
+                    load_b(lc, lt, bcur == 0 ? WB - 1 : bcur - 1);
+                    if (++lt == 9) { lt = 0; ++lc; }
+                } else {
+                    --ahead;                   // nothing left to request: the ring drains (full waits from here on)
+                }
+            } else {
+                if (t < 8) load_b(c, t + 1, bcur ^ 1);
+                else if (c + 1 < c_end) load_b(c + 1, 0, bcur ^ 1);
+            }
 #endif
-            if (!SPB && c + 1 < nchunks)
+            if (!SPB && c + 1 < c_end)
                 for (int sl = t; sl < slots; sl += 9) load_patch_piece(c + 1, sl);
             STAMP(3);
             // fragments of this tap
@@ -873,12 +1003,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, MINW) void conv3x3_halo_ker
                         }
                     }
             }
-            bcur ^= 1;
+            if constexpr (WB > 2) bcur = bcur + 1 == WB ? 0 : bcur + 1;
+            else bcur ^= 1;
 #ifdef YOLO_CONV_STAMPS
             asm volatile("s_nop 0" :: "v"(acc[0][0][0]));
             STAMP(4);
 #endif
         }
+    }
+    if (p.splitk > 1) {                // uniform: raw partial tile, the reduce launch finishes the layer
+        if constexpr (EPASS == 3 && MS == 16) store_partial_cols<TM, TN>(p, acc, blockIdx.y, m0, n0, wm0, wn0, lane);
+        else store_partial_rows<TM, TN, MS, AccT>(p, acc, blockIdx.y, m0, n0, wm0, wn0, fr, fh);
+        return;
     }
 #if defined(YOLO_EXP) && YOLO_EXP == 3          // EXP 3: no epilogue (accumulators kept live, one store per lane)
     {
@@ -1261,10 +1397,6 @@ static int launch_p8(const ConvK& k, hipStream_t stream) {
 //     vmcnt order per step: [weights s+1 (BI pieces)] ... [activations s+2 (4 loads)], so vmcnt(4) at the top of step s+1
 //     leaves exactly the youngest activation set in flight.
 #define GLOAD16(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr))
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
 // D: K-steps the loads run ahead (D activation register sets, D + 1 weight buffers); NW waves of 32 pixels x BN = 16 TN channels.
 // PERM: a lane's two loads are the adjacent 16-byte pieces 2 fq, 2 fq + 1 of the K-chunk (described above); !PERM: pieces fq and
 // 4 + fq (the plain fragment order: every load instruction reads 64 contiguous bytes per pixel).
@@ -1293,12 +1425,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) 
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int fr = lane & 15, fq = lane >> 4;
-    const int nsteps = p.nsteps;
+    // K slice of this workgroup (split-K: blockIdx.y; otherwise the whole K)
+    const int nsl = p.splitk > 1 ? (p.nsteps + p.splitk - 1) / p.splitk : p.nsteps;
+    const int s_begin = p.splitk > 1 ? (int)blockIdx.y * nsl : 0;
+    const int nsteps = (s_begin + nsl < p.nsteps ? s_begin + nsl : p.nsteps) - s_begin;
 
     // ---- weight loader: this lane fills slot (lane & 7) of row 8 g + (lane >> 3), g = wave + NW i
     const int phys = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);      // slot ^ swizzle(row) = 4 k + q of the stored chunk
     const int chunk = PERM ? 2 * (phys & 3) + (phys >> 2) : phys;             // ... which is logical k-chunk 2 q + k
-    const char* wsrc = p.w + (long long)(n0 + 8 * wave + (lane >> 3)) * p.kpad_bytes + chunk * 16;
+    const char* wsrc = p.w + (long long)(n0 + 8 * wave + (lane >> 3)) * p.kpad_bytes + chunk * 16 + s_begin * 128;
     const long long w_step = (long long)(8 * NW) * p.kpad_bytes;
     auto load_b = [&](int buf) {
         char* lb = lds + buf * B_BYTES + wave * 1024;
@@ -1312,7 +1447,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) 
     for (int i = 0; i < TM; ++i) {
         int m = m0 + wave * 32 + i * 16 + fr;
         m = m < p.M ? m : p.M - 1;
-        aptr[i] = p.in + ((long long)m * p.in_ld + p.in_coff) * 2 + fq * (PERM ? 32 : 16);
+        aptr[i] = p.in + ((long long)m * p.in_ld + p.in_coff) * 2 + fq * (PERM ? 32 : 16) + s_begin * 128;
     }
     int b_off[TN], b_sw[TN];
 #pragma unroll
@@ -1385,6 +1520,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) 
         for (int d = 0; d < D; ++d)
             if (s + d < nsteps) step(s + d, a[d]);
     }
+    if (p.splitk > 1) { store_partial_cols<TM, TN>(p, acc, blockIdx.y, m0, n0, wave * 32, 0, lane); return; }
 #if defined(YOLO_EXP) && YOLO_EXP == 9          // EXP 9: ... without epilogue
     {
         float sacc = 0.f;
@@ -1415,23 +1551,23 @@ static int launch_direct1x1(const ConvK& k, hipStream_t stream) {
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
     note_kernel("yolo::conv1x1_direct_kernel<%d, %d, %d, %d, %s>", NW, TN, D, MINW, PERM ? "true" : "false");
-    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * NW), lds_bytes, stream, kk);
+    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn, kk.splitk > 1 ? kk.splitk : 1), dim3(64 * NW), lds_bytes, stream, kk);
     YOLO_HIP_CHECK(hipGetLastError());
-    return YOLO_OK;
+    return kk.splitk > 1 ? launch_splitk_reduce(kk, stream) : YOLO_OK;
 }
 
-template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32, int EPASS = 1, int MINW = 1>
+template <bool BF16, int BM, int BN, int WARPS_M, int WARPS_N, bool SPB = false, int MS = 32, int EPASS = 1, int MINW = 1, int WB = 2>
 static int launch_halo(const ConvK& k, hipStream_t stream) {
-    if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32, EPASS == 3 ? 0 : EPASS, MINW>(k, stream);
+    if constexpr (MS == 16 && !BF16) return launch_halo<BF16, BM, BN, WARPS_M, WARPS_N, SPB, 32, EPASS == 3 ? 0 : EPASS, MINW, WB>(k, stream);
     else {
     const int prows = (int)align_up((size_t)(BM + 2 * k.W + 2), 8);
     const int nchunks = k.Cin * (BF16 ? 2 : 4) / 128;
-    const int loop_bytes = ((nchunks > 1 && !SPB) ? 2 : 1) * prows * 128 + 2 * BN * 128 + 128;
+    const int loop_bytes = ((nchunks > 1 && !SPB) ? 2 : 1) * prows * 128 + WB * BN * 128 + 128;
     constexpr int epi_bytes = EPASS == 3 ? 0 : EPASS == 0 ? WARPS_M * WARPS_N * 32 * (BN / WARPS_N + 4) * 4 : BM / (EPASS ? EPASS : 1) * (BN + 4) * 4;
     const int lds_bytes = loop_bytes > epi_bytes ? loop_bytes : epi_bytes;
     YOLO_REQUIRE(lds_bytes <= 160 * 1024, YOLO_ERR_UNSUPPORTED, "conv3x3 halo: W=%d needs %d bytes of LDS", k.W, lds_bytes);
     YOLO_REQUIRE((long long)k.M * k.in_ld * (BF16 ? 2 : 4) < (1ll << 32), YOLO_ERR_SHAPE, "conv3x3 halo: input larger than 4 GiB");
-    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB, MS, EPASS, MINW>;
+    auto fn = conv3x3_halo_kernel<BF16, BM, BN, WARPS_M, WARPS_N, SPB, MS, EPASS, MINW, WB>;
     static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
@@ -1442,10 +1578,11 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS, EPASS, MINW);
-    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
+    if (WB == 2) note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS, EPASS, MINW);
+    else note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS, EPASS, MINW, WB);
+    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn, kk.splitk > 1 ? kk.splitk : 1), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
     YOLO_HIP_CHECK(hipGetLastError());
-    return YOLO_OK;
+    return kk.splitk > 1 ? launch_splitk_reduce(kk, stream) : YOLO_OK;
     }
 }
 
@@ -1473,9 +1610,9 @@ static int launch_cfg(const ConvK& k, hipStream_t stream) {
         note_kernel("yolo::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, STAGES);
     else
         note_kernel("yolo::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, STAGES, MS, EPASS, MINW);
-    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk);
+    hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn, kk.splitk > 1 ? kk.splitk : 1), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk);
     YOLO_HIP_CHECK(hipGetLastError());
-    return YOLO_OK;
+    return kk.splitk > 1 ? launch_splitk_reduce(kk, stream) : YOLO_OK;
     }
 }
 
@@ -1523,13 +1660,43 @@ static int env_map_cfg(const char* var, int ksize, int w) {       // "<W>=<cfg>,
 }
 #endif
 
+// Largest divisor S of `units` with tiles * S <= 512 workgroups and at least `min_units` K units per slice (1 = no split).
+static int pick_splitk(int tiles, int units, int min_units) {
+    int best = 1;
+    for (int s = 2; s <= units; ++s)
+        if (units % s == 0 && units / s >= min_units && (long long)tiles * s <= 512) best = s;
+    return best;
+}
+
 template <bool BF16>
-static int launch_dtype(const ConvK& k, hipStream_t stream) {
+static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
+    ConvK k = k_in;
     int cfg = forced_cfg();
     const int sz = BF16 ? 2 : 4;
     const bool plain = !k.upsample && !k.reorg && !k.out_f32;
     const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && plain;
     const bool direct_ok = BF16 && k.ksize == 1 && k.stride == 1 && plain && (k.Cin * 2) % 128 == 0;
+    // ---- small-batch plan (opt-in per handle): a layer whose 128 x 128 tiles would occupy fewer than half the CUs runs its
+    // K loop in S slices on S times as many workgroups (the latency of such a launch is its K-step chain, 0.5 - 1 us a step),
+    // f32 partial tiles + one reduce launch.  The sums are added in slice order, so the result is deterministic, but it is
+    // NOT bit-identical to the unsplit plan (within the bf16 tolerance: the f32 accumulation order differs).
+    if constexpr (BF16) {
+        if (k.partial && cfg < 0 && plain && k.Cout % 8 == 0) {
+            const int tiles = ((k.M + 127) / 128) * ((k.Cout + 127) / 128);
+            int S = 1, pick = -1;
+            if (tiles < 128) {
+                if (halo_ok) {
+                    if ((int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) { S = pick_splitk(tiles, k.Cin * 2 / 128, 1); pick = 68; }
+                }
+                // 1x1: a launch of up to 8 K steps already sits at the ~6 us floor of launch + first-load latency (measured at
+                // batch 1: 52x52 6.4 us split or not, 26x26 8.8 vs 6.0 + 4.0 for the reduce launch): only K >= 1024 gains
+                else if (direct_ok && k.Cout > 64 && k.nsteps >= 16) { S = pick_splitk(tiles, k.nsteps, 2); pick = 97; }
+                else if (k.ksize == 3 && k.stride == 2 && (k.Cin * 2) % 128 == 0 && k.Cout > 64) { S = pick_splitk(tiles, k.nsteps, 4); pick = 88; }
+            }
+            if (S > 1 && (long long)S * k.M * k.Cout <= k.partial_cap) { k.splitk = S; cfg = pick; }
+        }
+    }
+    if (k.splitk <= 1) { k.splitk = 1; k.partial = nullptr; }
 #ifdef YOLO_EXPERIMENTAL_TILINGS
     if (halo_ok && cfg < 0) cfg = env_map_cfg("YOLO_HALO_CFG", 0, k.W);
     if (cfg >= 43 && cfg <= 46) {                               // ping-pong tile on the small (43, 44) / large (45, 46) maps only
@@ -1609,6 +1776,10 @@ static int launch_dtype(const ConvK& k, hipStream_t stream) {
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
 #ifdef YOLO_EXPERIMENTAL_TILINGS
+        // 68 with a six- / four-deep weight ring behind counted waits: at batch 1 a 9-step K slice took 15.0 us either way (the
+        // chain is launch + first-load latency + one wave per SIMD reading LDS and issuing MFMAs back to back, not the weight tiles)
+        case 76: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2, 6>(k, stream);
+        case 77: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2, 4>(k, stream);
         case 0: return launch_cfg<BF16, 128, 128, 2, 2, 2>(k, stream);     // 2 blocks/CU
         case 1: return launch_cfg<BF16, 256, 128, 4, 2, 3>(k, stream);     // 8 waves, 3-stage ring, 1 block/CU
         case 2: return launch_cfg<BF16, 128, 128, 2, 2, 3>(k, stream);     // 4 waves, 3-stage ring, 1 block/CU
@@ -1693,6 +1864,9 @@ int launch_conv_igemm(int dtype, const ConvLaunch& p, hipStream_t stream) {
     const long long M = (long long)p.B * p.Ho * p.Wo;
     YOLO_REQUIRE(M > 0 && M < (1ll << 31) - 512, YOLO_ERR_SHAPE, "conv: M=%lld out of range", M);
     k.M = (int)M; k.ntm = k.ntn = 0;
+    k.splitk = 1;
+    k.partial = (p.small_plan && p.scratch && ((uintptr_t)p.scratch & 15) == 0) ? (float*)p.scratch : nullptr;
+    k.partial_cap = (long long)(p.scratch_bytes / 4);
     return dtype == YOLO_DTYPE_BF16 ? launch_dtype<true>(k, stream) : launch_dtype<false>(k, stream);
 }
 

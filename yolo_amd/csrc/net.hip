@@ -217,11 +217,14 @@ struct Step {
     int reorg;
 };
 struct Tens { int h, w, ld; size_t bytes; int first, last; size_t offset; };
-struct Plan { std::vector<Step> steps; std::vector<Tens> tens; size_t ws_bytes = 0; };
+struct Plan { std::vector<Step> steps; std::vector<Tens> tens; size_t ws_bytes = 0; size_t scratch_off = 0, scratch_bytes = 0; };
+// split-K partial tiles of the small-batch plan: at most 512 workgroups x 128 x 128 f32 per launch (conv_igemm.hip pick_splitk)
+constexpr size_t kSplitKScratch = (size_t)512 * 128 * 128 * 4;
 
 struct YoloNet {
     int kind = 3;              // 3: YOLOv3 (model.py), 2: YOLOv2 (yolo_v2.py)
     int class_num = 0, dtype = 0, box_per_cell = 5;
+    bool small_plan = false;   // yolo_net_set_small_batch_plan
     std::vector<std::string> kernel_names;   // per layer, filled by yolo_net_forward_timed
     std::vector<Spec> specs;
     std::vector<std::unique_ptr<ConvParams>> layers;
@@ -399,8 +402,15 @@ static int get_plan(YoloNet* net, int B, int H, int W, const Plan** out) {
     std::lock_guard<std::mutex> g(net->mu);
     auto key = std::make_tuple(B, H, W);
     auto it = net->plans.find(key);
-    if (it == net->plans.end())
-        it = net->plans.emplace(key, net->kind == 2 ? build_plan_v2(*net, B, H, W) : build_plan(*net, B, H, W)).first;
+    if (it == net->plans.end()) {
+        Plan P = net->kind == 2 ? build_plan_v2(*net, B, H, W) : build_plan(*net, B, H, W);
+        if (net->small_plan && net->dtype == YOLO_DTYPE_BF16) {
+            P.scratch_off = align_up(P.ws_bytes, 256);
+            P.scratch_bytes = kSplitKScratch;
+            P.ws_bytes = P.scratch_off + P.scratch_bytes;
+        }
+        it = net->plans.emplace(key, std::move(P)).first;
+    }
     *out = &it->second;
     return YOLO_OK;
 }
@@ -498,6 +508,17 @@ extern "C" int yolo_net_destroy(YoloNet* net) {
     return YOLO_OK;
 }
 
+// Small-batch plan (no counterpart in the reference): see include/yolo_hip.h.
+extern "C" int yolo_net_set_small_batch_plan(YoloNet* net, int on) {
+    YOLO_REQUIRE(net, YOLO_ERR_ARG, "set_small_batch_plan: null handle");
+    std::lock_guard<std::mutex> g(net->mu);
+    if (net->small_plan != (on != 0)) {
+        net->small_plan = on != 0;
+        net->plans.clear();                    // workspace sizes change with the scratch area
+    }
+    return YOLO_OK;
+}
+
 extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->layers.size() : 0; }
 
 // ---- lanes ------------------------------------------------------------------------------------------
@@ -592,6 +613,11 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
         }
         p.upsample = st.upsample;
         p.reorg = st.reorg;
+        if (P->scratch_bytes) {
+            p.small_plan = 1;
+            p.scratch = (char*)workspace + P->scratch_off;
+            p.scratch_bytes = P->scratch_bytes;
+        }
         if (events) YOLO_HIP_CHECK(hipEventRecord(events[st.layer], (hipStream_t)stream));
         if (fuse_front && st.layer == 0) {        // held back: launched together with layer 1 (front.hip)
             front_p = p;

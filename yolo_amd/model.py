@@ -18,13 +18,15 @@ from .utils import misc_utils
 
 class yolov3(object):
 
-    def __init__(self, class_num, anchors, batch_norm_decay=0.9, dtype="fp32"):
-        # model.py:16-19 (batch_norm_decay only matters for training; kept for signature parity)
+    def __init__(self, class_num, anchors, batch_norm_decay=0.9, dtype="fp32", small_batch_plan=False):
+        # model.py:16-19 (batch_norm_decay only matters for training; kept for signature parity).  small_batch_plan: bf16 only,
+        # split-K launches for layers whose grid would leave most CUs idle (batch 1 - 4 latency; include/yolo_hip.h)
         self.class_num = class_num
         self.anchors = np.asarray(anchors, np.float32).reshape(-1, 2)
         self.batch_norm_decay = batch_norm_decay
         self.dtype = dtype
         self._dtype_code = _lib.DTYPES[dtype]
+        self.small_batch_plan = bool(small_batch_plan)
         self._net = None
         self._ws = None
         self._post_ws = None
@@ -55,6 +57,8 @@ class yolov3(object):
                                               stream.size, ctypes.byref(h)))
         self._net = h
         self._device = torch.cuda.current_device()               # the packed weights live on this GPU
+        if self.small_batch_plan:
+            _lib.check(_lib.lib().yolo_net_set_small_batch_plan(self._net, 1))
         return self
 
     def _check_ready(self, x):
