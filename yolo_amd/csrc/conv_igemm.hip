@@ -1578,8 +1578,7 @@ static int launch_halo(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    if (WB == 2) note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS, EPASS, MINW);
-    else note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS, EPASS, MINW, WB);
+    note_kernel("yolo::conv3x3_halo_kernel<%s, %d, %d, %d, %d, %s, %d, %d, %d, %d>", BF16 ? "true" : "false", BM, BN, WARPS_M, WARPS_N, SPB ? "true" : "false", MS, EPASS, MINW, WB);
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn, kk.splitk > 1 ? kk.splitk : 1), dim3(64 * WARPS_M * WARPS_N), lds_bytes, stream, kk, prows);
     YOLO_HIP_CHECK(hipGetLastError());
     return kk.splitk > 1 ? launch_splitk_reduce(kk, stream) : YOLO_OK;
