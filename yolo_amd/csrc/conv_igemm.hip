@@ -1400,8 +1400,12 @@ static int launch_p8(const ConvK& k, hipStream_t stream) {
 // D: K-steps the loads run ahead (D activation register sets, D + 1 weight buffers); NW waves of 32 pixels x BN = 16 TN channels.
 // PERM: a lane's two loads are the adjacent 16-byte pieces 2 fq, 2 fq + 1 of the K-chunk (described above); !PERM: pieces fq and
 // 4 + fq (the plain fragment order: every load instruction reads 64 contiguous bytes per pixel).
-template <int NW, int TN, int D, int MINW, bool PERM = true>
+// TAPS: the same kernel for a 3x3 convolution of any stride (the stride-2 layers, whose patch is too large for the LDS-patch
+// kernel): K-step s is (tap s / chunks, chunk s % chunks); the lane's pixel pointer moves to the tap's input pixel, out-of-image
+// taps read a zero page - the im2col gather done by address arithmetic instead of through LDS.
+template <int NW, int TN, int D, int MINW, bool PERM = true, bool TAPS = false>
 __global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) {
+    static_assert(!(TAPS && PERM), "tap addressing uses the plain piece order");
     constexpr int TM = 2;
     constexpr int BM = NW * 32, BN = TN * 16;
     constexpr int B_BYTES = BN * 128;
@@ -1443,11 +1447,32 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) 
     };
     // ---- activation rows of this lane (rows past M are clamped; the epilogue drops them)
     const char* aptr[TM];
+    unsigned amask[TM];                               // TAPS: bit t = tap t of this pixel lies inside the image
+    const int CinB = p.Cin * 2;
+    const int pix_b = p.in_ld * 2;
+    int ltap = 0, lcib = s_begin * 128;               // TAPS: tap and channel byte offset of the next activation load
+    if constexpr (TAPS) while (lcib >= CinB) { lcib -= CinB; ++ltap; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int m = m0 + wave * 32 + i * 16 + fr;
         m = m < p.M ? m : p.M - 1;
-        aptr[i] = p.in + ((long long)m * p.in_ld + p.in_coff) * 2 + fq * (PERM ? 32 : 16) + s_begin * 128;
+        if constexpr (TAPS) {
+            const int HoWo = p.Ho * p.Wo;
+            const int b = m / HoWo, r = m - b * HoWo;
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            aptr[i] = p.in + (((long long)b * p.H + iy0) * p.W + ix0) * pix_b + p.in_coff * 2 + fq * 16;
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+            }
+            amask[i] = mask;
+        } else {
+            aptr[i] = p.in + ((long long)m * p.in_ld + p.in_coff) * 2 + fq * (PERM ? 32 : 16) + s_begin * 128;
+            amask[i] = 0;
+        }
     }
     int b_off[TN], b_sw[TN];
 #pragma unroll
@@ -1464,12 +1489,25 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) 
 
     u32x4 a[D][TM][2];                                // register set d: K-steps s with s % D == d
     auto load_a = [&](u32x4 (&x)[TM][2]) {
+        if constexpr (TAPS) {
+            const int ky = (ltap * 11) >> 5, kx = ltap - ky * 3;
+            const long long toff = (long long)(ky * p.W + kx) * pix_b + lcib;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            GLOAD16(x[i][0], aptr[i], 0);
-            if constexpr (PERM) GLOAD16(x[i][1], aptr[i], 16);
-            else GLOAD16(x[i][1], aptr[i], 64);
-            aptr[i] += 128;
+            for (int i = 0; i < TM; ++i) {
+                const char* src = ((amask[i] >> ltap) & 1) ? aptr[i] + toff : (const char*)g_zero_page + fq * 16;
+                GLOAD16(x[i][0], src, 0);
+                GLOAD16(x[i][1], src, 64);
+            }
+            lcib += 128;
+            if (lcib >= CinB) { lcib = 0; ++ltap; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                GLOAD16(x[i][0], aptr[i], 0);
+                if constexpr (PERM) GLOAD16(x[i][1], aptr[i], 16);
+                else GLOAD16(x[i][1], aptr[i], 64);
+                aptr[i] += 128;
+            }
         }
     };
     auto compute = [&](const char* base, u32x4 (&x)[TM][2]) {
@@ -1533,13 +1571,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void conv1x1_direct_kernel(ConvK p) 
 }
 #undef GLOAD16
 
-template <int NW, int TN, int D, int MINW, bool PERM = true>
+template <int NW, int TN, int D, int MINW, bool PERM = true, bool TAPS = false>
 static int launch_direct1x1(const ConvK& k, hipStream_t stream) {
     constexpr int BM = NW * 32, BN = TN * 16;
     constexpr int lds_bytes = (D + 1) * BN * 128;
-    YOLO_REQUIRE(k.ksize == 1 && k.stride == 1 && (k.Cin * 2) % 128 == 0 && !k.upsample && !k.reorg && !k.out_f32, YOLO_ERR_UNSUPPORTED,
-                 "conv1x1 direct: plain bf16 1x1 stride-1 layers with Cin a multiple of 64 only");
-    auto fn = conv1x1_direct_kernel<NW, TN, D, MINW, PERM>;
+    YOLO_REQUIRE((TAPS ? k.ksize == 3 : (k.ksize == 1 && k.stride == 1)) && (k.Cin * 2) % 128 == 0 && !k.upsample && !k.reorg && !k.out_f32, YOLO_ERR_UNSUPPORTED,
+                 "conv direct: plain bf16 1x1 stride-1 (3x3 for the tap variant) layers with Cin a multiple of 64 only");
+    auto fn = conv1x1_direct_kernel<NW, TN, D, MINW, PERM, TAPS>;
     static std::atomic<bool> attr_done[16];
     int dev = 0;
     YOLO_HIP_CHECK(hipGetDevice(&dev));
@@ -1550,7 +1588,7 @@ static int launch_direct1x1(const ConvK& k, hipStream_t stream) {
     ConvK kk = k;
     kk.ntm = (k.M + BM - 1) / BM;
     kk.ntn = (k.Cout + BN - 1) / BN;
-    note_kernel("yolo::conv1x1_direct_kernel<%d, %d, %d, %d, %s>", NW, TN, D, MINW, PERM ? "true" : "false");
+    note_kernel("yolo::conv1x1_direct_kernel<%d, %d, %d, %d, %s, %s>", NW, TN, D, MINW, PERM ? "true" : "false", TAPS ? "true" : "false");
     hipLaunchKernelGGL(fn, dim3(kk.ntm * kk.ntn, kk.splitk > 1 ? kk.splitk : 1), dim3(64 * NW), lds_bytes, stream, kk);
     YOLO_HIP_CHECK(hipGetLastError());
     return kk.splitk > 1 ? launch_splitk_reduce(kk, stream) : YOLO_OK;
@@ -1675,6 +1713,7 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
     const bool plain = !k.upsample && !k.reorg && !k.out_f32;
     const bool halo_ok = k.ksize == 3 && k.stride == 1 && (k.Cin * sz) % 128 == 0 && k.Cout > 64 && plain;
     const bool direct_ok = BF16 && k.ksize == 1 && k.stride == 1 && plain && (k.Cin * 2) % 128 == 0;
+    const bool direct3_ok = BF16 && k.ksize == 3 && plain && (k.Cin * 2) % 128 == 0 && k.Cout > 64;
     // ---- small-batch plan (opt-in per handle): a layer whose 128 x 128 tiles would occupy fewer than half the CUs runs its
     // K loop in S slices on S times as many workgroups (the latency of such a launch is its K-step chain, 0.5 - 1 us a step),
     // f32 partial tiles + one reduce launch.  The sums are added in slice order, so the result is deterministic, but it is
@@ -1718,7 +1757,8 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
 #endif
     if (cfg == 75) cfg = !halo_ok ? -1 : k.W <= 16 ? 73 : k.W <= 52 ? 72 : 74;   // the shipped tile choice with the register epilogue
     if (cfg >= 80 && cfg < 90 && (halo_ok || k.Cout <= 64)) cfg = -1;
-    if (cfg >= 90 && cfg < 100 && !direct_ok) cfg = -1;
+    if (cfg >= 90 && cfg < 98 && !direct_ok) cfg = -1;
+    if (cfg >= 98 && cfg < 104 && (!direct3_ok || k.stride == 1)) cfg = -1;   // forced: the stride-2 layers only
     if (cfg >= 20 && cfg < 80 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
@@ -1744,6 +1784,9 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
         // pixel row) a launch on cold inputs is slower (28 vs 25 us) but the step is 0.5 - 1 % faster (three interleaved A/B runs
         // of 100 steps): in the network the rows come from L2 / MALL and the small LDS footprint lets other lanes' kernels share the CU.
         else if (direct_ok) cfg = 97;
+        // stride-2 3x3 layers: the same kernel with tap addressing (their patch does not fit the LDS-patch kernel at two
+        // workgroups per CU); 0.6 - 0.8 % per step over the im2col kernel in two interleaved A/B sessions of 3 x 60 steps
+        else if (direct3_ok && k.stride == 2) cfg = 98;
         else cfg = (BF16 && plain) ? 88 : 5;   // 88: 5 on 16x16x32 MFMAs with the register epilogue (+8 % on the 1x1 layers)
     }
     switch (cfg) {
@@ -1771,10 +1814,20 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
                 }
             }
             return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 98: case 99:                                                   // direct-A kernel on a 3x3 conv (tap addressing), 8 / 4 waves
+            if constexpr (BF16) {
+                if (direct3_ok) return cfg & 1 ? launch_direct1x1<4, 8, 2, 2, false, true>(k, stream) : launch_direct1x1<8, 8, 2, 2, false, true>(k, stream);
+            }
+            return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
         case 12: return launch_cfg<BF16, 256, 64, 4, 2, 2>(k, stream);     // 8 waves
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
 #ifdef YOLO_EXPERIMENTAL_TILINGS
+        case 100: case 101:                                                 // 98 / 99 three K-steps ahead
+            if constexpr (BF16) {
+                if (direct3_ok) return cfg & 1 ? launch_direct1x1<4, 8, 3, 2, false, true>(k, stream) : launch_direct1x1<8, 8, 3, 2, false, true>(k, stream);
+            }
+            return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
         // 68 with a six- / four-deep weight ring behind counted waits: at batch 1 a 9-step K slice took 15.0 us either way (the
         // chain is launch + first-load latency + one wave per SIMD reading LDS and issuing MFMAs back to back, not the weight tiles)
         case 76: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2, 6>(k, stream);
