@@ -255,7 +255,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK p) {
     const long long slice = (long long)p.M * p.Cout;
     const float* src = p.partial + (long long)m * p.Cout + n;
     f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
-    for (int s = 1; s < p.splitk; ++s) {
+    // four slices' loads in flight at a time (a slice-by-slice loop is a chain of S memory latencies); the adds stay in slice order
+    int s = 1;
+    for (; s + 3 < p.splitk; s += 4) {
+        f32x4 b[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { b[u][0] = *(const f32x4*)(src + (s + u) * slice); b[u][1] = *(const f32x4*)(src + (s + u) * slice + 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] += b[u][0][e]; a1[e] += b[u][1][e]; }
+    }
+    for (; s < p.splitk; ++s) {
         const f32x4 b0 = *(const f32x4*)(src + s * slice), b1 = *(const f32x4*)(src + s * slice + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a0[e] += b0[e]; a1[e] += b1[e]; }
@@ -1724,13 +1735,22 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
             int S = 1, pick = -1;
             if (tiles < 128) {
                 if (halo_ok) {
-                    if ((int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) { S = pick_splitk(tiles, k.Cin * 2 / 128, 1); pick = 68; }
+                    if ((int)align_up((size_t)(128 + 2 * k.W + 2), 8) * 128 + 2 * 128 * 128 + 128 <= 160 * 1024) {
+                        // eight waves of 32 x 64 on 32x32x16 MFMAs: a short slice at one workgroup per CU is a chain of LDS-read and
+                        // load latencies (stamps at batch 1: 470 wait + 220 issue + 920 fragment/MFMA cycles per step for 512 MFMA
+                        // cycles), which two waves per SIMD overlap: batch-1 forward 0.965 ms with the four-wave tile 68, 0.893
+                        // with 69, 0.877 with 24, 0.867 with 28; 16 waves of 32 x 32 0.88 - 0.91
+                        S = pick_splitk(tiles, k.Cin * 2 / 128, 1); pick = 28;
+                    }
                 }
                 // 1x1: a launch of up to 8 K steps already sits at the ~6 us floor of launch + first-load latency (measured at
                 // batch 1: 52x52 6.4 us split or not, 26x26 8.8 vs 6.0 + 4.0 for the reduce launch): only K >= 1024 gains
                 else if (direct_ok && k.Cout > 64 && k.nsteps >= 16) { S = pick_splitk(tiles, k.nsteps, 2); pick = 97; }
-                else if (k.ksize == 3 && k.stride == 2 && (k.Cin * 2) % 128 == 0 && k.Cout > 64) { S = pick_splitk(tiles, k.nsteps, 4); pick = 88; }
+                else if (direct3_ok && k.stride == 2) { S = pick_splitk(tiles, k.nsteps, 4); pick = 98; }
             }
+#ifdef YOLO_EXPERIMENTAL_TILINGS
+            if (pick == 28) { static const int e = [] { const char* v = getenv("YOLO_SPLIT_HALO_CFG"); return v ? atoi(v) : 0; }(); if (e > 0) pick = e; }
+#endif
             if (S > 1 && (long long)S * k.M * k.Cout <= k.partial_cap) { k.splitk = S; cfg = pick; }
         }
     }
@@ -1758,7 +1778,8 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
     if (cfg == 75) cfg = !halo_ok ? -1 : k.W <= 16 ? 73 : k.W <= 52 ? 72 : 74;   // the shipped tile choice with the register epilogue
     if (cfg >= 80 && cfg < 90 && (halo_ok || k.Cout <= 64)) cfg = -1;
     if (cfg >= 90 && cfg < 98 && !direct_ok) cfg = -1;
-    if (cfg >= 98 && cfg < 104 && (!direct3_ok || k.stride == 1)) cfg = -1;   // forced: the stride-2 layers only
+    if (cfg >= 98 && cfg < 102 && (!direct3_ok || k.stride == 1)) cfg = -1;   // forced: the stride-2 layers only
+    if (cfg >= 102 && cfg < 104 && (!direct3_ok || k.stride != 1 || k.W <= 64)) cfg = -1;   // XP: the 104 x 104 stride-1 layers
     if (cfg >= 20 && cfg < 80 && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
@@ -1823,6 +1844,13 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
         case 14: return launch_cfg<BF16, 128, 64, 4, 2, 2>(k, stream);     // 8 waves, small tile
         case 10: return launch_cfg<BF16, 256, 32, 4, 1, 2>(k, stream);
 #ifdef YOLO_EXPERIMENTAL_TILINGS
+        case 102: case 103:                                                 // 98 / 99 on the stride-1 layers of the widest map
+            if constexpr (BF16) {
+                if (direct3_ok) return cfg & 1 ? launch_direct1x1<4, 8, 2, 2, false, true>(k, stream) : launch_direct1x1<8, 8, 2, 2, false, true>(k, stream);
+            }
+            return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 78: return launch_halo<BF16, 128, 128, 4, 4, true, 16, 0, 1>(k, stream);    // 128 x 128 as 16 waves of 32 x 32 (small-batch slices)
+        case 79: return launch_halo<BF16, 128, 128, 4, 4, false, 32, 1, 1>(k, stream);
         case 100: case 101:                                                 // 98 / 99 three K-steps ahead
             if constexpr (BF16) {
                 if (direct3_ok) return cfg & 1 ? launch_direct1x1<4, 8, 3, 2, false, true>(k, stream) : launch_direct1x1<8, 8, 3, 2, false, true>(k, stream);
