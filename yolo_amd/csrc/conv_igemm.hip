@@ -1780,7 +1780,7 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
     if (cfg >= 90 && cfg < 98 && !direct_ok) cfg = -1;
     if (cfg >= 98 && cfg < 102 && (!direct3_ok || k.stride == 1)) cfg = -1;   // forced: the stride-2 layers only
     if (cfg >= 102 && cfg < 104 && (!direct3_ok || k.stride != 1 || k.W <= 64)) cfg = -1;   // XP: the 104 x 104 stride-1 layers
-    if (cfg >= 20 && cfg < 80 && !halo_ok) cfg = -1;
+    if (((cfg >= 20 && cfg < 80) || (cfg >= 110 && cfg < 120)) && !halo_ok) cfg = -1;
     if (cfg >= 0 && cfg < 10 && k.Cout <= 64) cfg = -1;
     if (cfg >= 10 && cfg < 20 && (k.Cout > 64)) cfg = -1;
     if (cfg < 0) {
@@ -1849,6 +1849,13 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
                 if (direct3_ok) return cfg & 1 ? launch_direct1x1<4, 8, 2, 2, false, true>(k, stream) : launch_direct1x1<8, 8, 2, 2, false, true>(k, stream);
             }
             return launch_cfg<BF16, 128, 128, 4, 2, 2>(k, stream);
+        case 110: case 111:                                                 // 70 / 61 with a three-deep weight ring behind counted waits
+            if constexpr (BF16) {
+                if (cfg == 110) return launch_halo<true, 192, 128, 4, 2, true, 16, 0, 4, 3>(k, stream);
+                return launch_halo<true, 256, 128, 4, 2, true, 16, 0, 4, 3>(k, stream);
+            }
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
+        case 112: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2, 3>(k, stream);   // 68 with a three-deep ring
         case 78: return launch_halo<BF16, 128, 128, 4, 4, true, 16, 0, 1>(k, stream);    // 128 x 128 as 16 waves of 32 x 32 (small-batch slices)
         case 79: return launch_halo<BF16, 128, 128, 4, 4, false, 32, 1, 1>(k, stream);
         case 100: case 101:                                                 // 98 / 99 three K-steps ahead
