@@ -527,15 +527,15 @@ extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->
 // GPU: the partly filled last round of workgroups of one launch (e.g. 676 tiles on 512 slots) and the drain / fill
 // between dependent launches are covered by the other lane's kernels.  Results do not depend on the split: every
 // output element is accumulated in the same order whatever tile or batch it is part of.
-// Default, by the work of the call in 416 x 416 images (B * H * W / 416^2): 2 lanes from 16 up, 3 from 56 up (round-2 kernels,
-// one MI355X: batch 12 one lane 2.02 ms vs two 2.13; batch 16 2.19 / 2.15; batch 32 3.11 / 2.87; batch 48 3.85 / 3.73 / 3.82
-// for 1 / 2 / 3 lanes; batch 64 5.18 / 4.91 / 4.88; 608 x 608 batch 16 3.49 / 3.36 / 3.35).
+// Default, by the work of the call in 416 x 416 images (B * H * W / 416^2): 2 lanes from 26 up, 3 from 56 up (round-3 kernels,
+// one MI355X, ms per detect call for 1 / 2 / 3 lanes: batch 16 2.17 / 2.21; 20 2.26 / 2.32 / 2.44; 24 2.40 / 2.45 / 2.59;
+// 28 2.98 / 2.75 / 2.74; 40 3.47 / 3.28 / 3.32; 48 3.76 / 3.64 / 3.73; 56 4.73 / 4.29 / 4.20; 608 x 608 batch 8 (work 17) 2.33 / 2.44).
 // YOLO_LANES=<n> in the environment (read per call) sets the number of lanes; 1 = one launch per layer for the whole batch.
 constexpr int MAX_LANES = 8;
 static int lane_count(int B, int H, int W) {
     const char* e = getenv("YOLO_LANES");
     const long long work = (long long)B * H * W / (416 * 416);
-    int n = e ? atoi(e) : (work >= 56 ? 3 : work >= 16 ? 2 : 1);
+    int n = e ? atoi(e) : (work >= 56 ? 3 : work >= 26 ? 2 : 1);
     if (n < 1) n = 1;
     if (n > MAX_LANES) n = MAX_LANES;
     return n < B ? n : B;
