@@ -62,7 +62,7 @@ int yolo_net_forward(YoloNet* net, const float* images, int B, int H, int W, voi
                      size_t workspace_bytes, float* fm1, float* fm2, float* fm3, void* stream);
 /* Small-batch ("latency") plan, bf16 handles, no counterpart in the reference (whose published operating point is batch 1,
  * yolo_v3/README.md:66).  At batch 1 - 4 a layer's grid covers a fraction of the 256 CUs and its time is the chain of its K-steps;
- * with the plan on, every 1x1 / 3x3 layer whose 128 x 128 tiles would occupy fewer than half the CUs runs its K loop in S slices
+ * with the plan on, every 3x3 layer (and 1x1 layer of K >= 1024) whose 128 x 128 tiles would occupy fewer than half the CUs runs its K loop in S slices
  * on S times as many workgroups (f32 partial tiles in the workspace) followed by one launch that adds the slices in order and
  * applies bias / activation / shortcut.  Deterministic, within the bf16 tolerance of the default plan but NOT bit-identical to it
  * (the f32 accumulation order differs), which is why it is opt-in: the default plan gives every image the same bits whatever

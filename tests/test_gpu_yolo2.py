@@ -106,6 +106,24 @@ def test_build_networks_bf16_vs_oracle(v2_bf16, v2_params, O2):
     assert float(np.sqrt(np.mean(err.astype(np.float64) ** 2))) <= 3e-2 * rms
 
 
+def test_stem_pool_fusion_equals_separate_kernels(v2_bf16):
+    """bf16 plan: the stem conv and the max-pool behind it run as one kernel (stem.hip POOL); YOLO_NO_STEM_POOL_FUSION=1
+    keeps them apart.  The pool of the bf16-rounded activations equals the rounded pool of the f32 ones (rounding is
+    monotonic), so the logits agree bit for bit; also on a rectangular input and with lanes."""
+    import os
+    import torch
+    rng = np.random.default_rng(41)
+    for B, H, W in ((3, 96, 96), (2, 64, 160), (40, 64, 64)):
+        x = (rng.random((B, H, W, 3), dtype=np.float32) * 2 - 1)
+        fused = v2_bf16.build_networks(x).clone()
+        os.environ["YOLO_NO_STEM_POOL_FUSION"] = "1"
+        try:
+            apart = v2_bf16.build_networks(x).clone()
+        finally:
+            del os.environ["YOLO_NO_STEM_POOL_FUSION"]
+        assert torch.equal(fused, apart), float((fused - apart).abs().max())
+
+
 def test_layerwise_composition_equals_fused_plan(v2_f32, O2):
     """build_networks written with the layer-level drop-ins (the reference's own structure, yolo_v2.py:34-68)
     gives the fused plan's logits."""

@@ -59,6 +59,7 @@ struct ConvLaunch {
     int small_plan;        // 1: the launcher may split K
     void* scratch;         // >= S * M * Cout * 4 bytes when small_plan
     size_t scratch_bytes;
+    int pool2x2;           // stem only (bf16): the output is the 2x2 / stride-2 max-pool of the conv's output (yolo_v2.py:34-35 fused)
 };
 
 // Measurement aid: when `record_kernel_names` is set (only yolo_net_forward_timed sets it), every launcher

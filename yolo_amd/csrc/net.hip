@@ -585,7 +585,13 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
     ConvLaunch front_p, res_p;
     memset(&front_p, 0, sizeof(front_p));
     memset(&res_p, 0, sizeof(res_p));
+    // bf16 YOLOv2: the stem conv and the max-pool behind it run as ONE kernel (stem.hip POOL) when the pool is the stem
+    // output's only reader (YOLO_NO_STEM_POOL_FUSION=1 keeps them apart, for A/B measurements and the equality test)
+    const char* np_env = getenv("YOLO_NO_STEM_POOL_FUSION");
+    const bool fuse_stem_pool = net->dtype == YOLO_DTYPE_BF16 && !(np_env && atoi(np_env) != 0);
+    bool skip_pool = false;
     for (const Step& st : P->steps) {
+        if (st.layer < 0 && skip_pool) { skip_pool = false; continue; }     // done by the stem launch before it
         if (st.layer < 0) {                       // pooling_layer (yolo_v2.py:91-94)
             const Tens& ti = P->tens[st.in];
             const Tens& to = P->tens[st.out];
@@ -613,6 +619,19 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
         }
         p.upsample = st.upsample;
         p.reorg = st.reorg;
+        if (fuse_stem_pool && L.stem && st.out >= 0 && st.res < 0 && p.H % 2 == 0 && p.W % 16 == 0) {
+            const size_t si = (size_t)(&st - P->steps.data());
+            if (si + 1 < P->steps.size() && P->steps[si + 1].layer < 0 && P->steps[si + 1].in == st.out) {
+                int readers = 0;
+                for (const Step& o : P->steps) readers += (o.in == st.out) + (o.res == st.out);
+                if (readers == 1) {
+                    const Tens& to = P->tens[P->steps[si + 1].out];
+                    p.out = (char*)workspace + to.offset; p.out_ld = to.ld; p.out_coff = 0;
+                    p.pool2x2 = 1;
+                    skip_pool = true;
+                }
+            }
+        }
         if (P->scratch_bytes) {
             p.small_plan = 1;
             p.scratch = (char*)workspace + P->scratch_off;
