@@ -75,6 +75,7 @@ int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream);   // Cin = 
 int launch_front(const ConvLaunch& stem, const ConvLaunch& down, hipStream_t stream);
 // res_block(x, 32): conv 64->32 (1x1) + conv 32->64 (3x3) + shortcut fused, bf16 only (resblock.hip)
 int launch_res_block(const ConvLaunch& c1, const ConvLaunch& c3, hipStream_t stream);
+int launch_conv3x3_c32_pool(const ConvLaunch& c3, hipStream_t stream);   // resblock.hip: conv 32->64 3x3 + 2x2 max-pool, bf16
 int launch_maxpool2x2(int dtype, const void* in, int B, int H, int W, int C, void* out, hipStream_t stream);
 int launch_cast_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 int launch_cast_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t stream);

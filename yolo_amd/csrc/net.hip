@@ -619,6 +619,21 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
         }
         p.upsample = st.upsample;
         p.reorg = st.reorg;
+        bool c32_pool = false;
+        if (fuse_stem_pool && !L.stem && L.cin == 32 && L.cout == 64 && L.k == 3 && L.stride == 1 && L.bn && st.out >= 0 && st.res < 0 &&
+            !st.upsample && !st.reorg && p.H % 8 == 0 && p.W % 16 == 0) {              // YOLOv2's second conv + pool (resblock.hip)
+            const size_t si = (size_t)(&st - P->steps.data());
+            if (si + 1 < P->steps.size() && P->steps[si + 1].layer < 0 && P->steps[si + 1].in == st.out) {
+                int readers = 0;
+                for (const Step& o : P->steps) readers += (o.in == st.out) + (o.res == st.out);
+                if (readers == 1) {
+                    const Tens& to = P->tens[P->steps[si + 1].out];
+                    p.out = (char*)workspace + to.offset; p.out_ld = to.ld; p.out_coff = 0;
+                    c32_pool = true;
+                    skip_pool = true;
+                }
+            }
+        }
         if (fuse_stem_pool && L.stem && st.out >= 0 && st.res < 0 && p.H % 2 == 0 && p.W % 16 == 0) {
             const size_t si = (size_t)(&st - P->steps.data());
             if (si + 1 < P->steps.size() && P->steps[si + 1].layer < 0 && P->steps[si + 1].in == st.out) {
@@ -700,7 +715,12 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
             if (dbl & cls) { rc = run_conv(L, p, (hipStream_t)stream); if (rc != YOLO_OK) return rc; }
         }
 #endif
-        rc = run_conv(L, p, (hipStream_t)stream);
+        if (c32_pool) {
+            fill_conv(L, p);
+            rc = launch_conv3x3_c32_pool(p, (hipStream_t)stream);
+        } else {
+            rc = run_conv(L, p, (hipStream_t)stream);
+        }
         if (rc != YOLO_OK) return rc;
         if (record_kernel_names) net->kernel_names[st.layer] = last_kernel_name();
     }
