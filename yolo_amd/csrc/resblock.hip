@@ -11,8 +11,10 @@
 //      consecutive channels of ONE pixel), bias + leaky, zero where the pixel lies outside the map (the 3x3 conv's
 //      SAME padding), bf16 -> LDS in planes [channel chunk of 8][pixel][16 B] (conflict-free fragment reads).
 //   3. 3x3 conv as an implicit GEMM out of LDS: per wave 32 pixels x 32 channels, 18 k-slices; weights [64][288]
-//      bf16 staged once per workgroup.  bias + leaky, + shortcut (read from the input patch), bf16 -> LDS staging
-//      -> 16-byte stores, 128 contiguous bytes per pixel.
+//      bf16 staged once per workgroup.  bias + leaky, + shortcut (read from the input patch and replaced in place by
+//      the result) -> 16-byte stores, 128 contiguous bytes per pixel.
+// Round 3: no staging tile (in-place result), biases in LDS: 93 -> 75 KB of LDS and 156 -> <= 128 VGPRs, two workgroups
+// (32 waves) per CU.
 // Same products, accumulation order and roundings as the two separate kernels: the results are bit-identical.
 #include <cstdlib>
 #include "common.h"
@@ -22,6 +24,7 @@ namespace yolo {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct ResK {
@@ -35,7 +38,7 @@ struct ResK {
     int tiles_x, tiles_y, ntiles;
 };
 
-constexpr int kResLds = 192 * 128 + 4 * 192 * 16 + 64 * 592 + 128 * 144;
+constexpr int kResLds = 192 * 128 + 4 * 192 * 16 + 64 * 592 + 96 * 4 + 32 * 144;
 
 template <int ACT>
 __device__ __forceinline__ float res_act(float v) {
@@ -44,17 +47,19 @@ __device__ __forceinline__ float res_act(float v) {
 }
 
 template <int ACT>
-__global__ __launch_bounds__(512) void res_block_kernel(ResK p) {
+__global__ __launch_bounds__(512, 4) void res_block_kernel(ResK p) {
     constexpr int NT = 512, TH = 8, PW = 18, NP = 180, NPP = 192;
     constexpr int XS_BYTES = NPP * 128, YPLANE = NPP * 16, YS_BYTES = 4 * YPLANE;
-    constexpr int W3_ROW = 592, W3_BYTES = 64 * W3_ROW, ST_ROW = 144;
+    constexpr int W3_ROW = 592, W3_BYTES = 64 * W3_ROW;
     constexpr int NE = (NP * 8 + NT - 1) / NT;         // 16-byte chunks of the input patch per thread
 
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     char* const xs = lds;
     char* const ys = xs + XS_BYTES;
     char* const w3s = ys + YS_BYTES;
-    char* const stage = w3s + W3_BYTES;
+    float* const b1s = (float*)(w3s + W3_BYTES);       // [32] + [64] biases (registers are needed elsewhere: <= 128 VGPRs)
+    float* const b3s = b1s + 32;
+    char* const w1s = (char*)(b3s + 64);               // 1x1 weights [32 cout][64 k] bf16, rows padded to 144 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,22 +68,16 @@ __global__ __launch_bounds__(512) void res_block_kernel(ResK p) {
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- once per workgroup ---------------------------------------------------------------------------------
+    if (tid < 32) b1s[tid] = p.b1[tid];
+    if (tid < 64) b3s[tid] = p.b3[tid];
     for (int i = tid; i < 64 * 36; i += NT) {          // 3x3 weights: 36 x 16 B per row of 288 bf16
         const int row = i / 36, ch = i - row * 36;
         *(u32x4*)(w3s + row * W3_ROW + ch * 16) = *(const u32x4*)(p.w3 + (long long)row * p.w3_row + ch * 16);
     }
     for (int i = tid; i < (NPP - NP) * 8; i += NT)     // pad pixels of the patch: never loaded, keep them finite
         *(u32x4*)(xs + NP * 128 + i * 16) = u32x4{0u, 0u, 0u, 0u};
-    bf16x8 w1f[4];                                     // 1x1 weights: A[row = cout fr][k = 16 q + 8 fh + j]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w1f[q] = *(const bf16x8*)(p.w1 + (long long)fr * p.w1_row + q * 32 + fh * 16);
-    float b1v[16], b3v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ch = (r & 3) + 8 * (r >> 2) + 4 * fh;
-        b1v[r] = p.b1[ch];
-        b3v[r] = p.b3[wn * 32 + ch];
-    }
+    if (tid < 32 * 8)                                  // 1x1 weights: A[row = cout fr][k = 16 q + 8 fh + j], read per tile from LDS
+        *(u32x4*)(w1s + (tid >> 3) * 144 + (tid & 7) * 16) = *(const u32x4*)(p.w1 + (long long)(tid >> 3) * p.w1_row + (tid & 7) * 16);
 
     const int per_img = p.tiles_x * p.tiles_y;
     const float inv_per_img = 1.0f / (float)per_img, inv_tx = 1.0f / (float)p.tiles_x;
@@ -152,7 +151,8 @@ __global__ __launch_bounds__(512) void res_block_kernel(ResK p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bf16x8 xf = *(const bf16x8*)(prow + (((2 * q + fh) ^ sw) << 4));   // B[k = 16 q + 8 fh + j][pixel]
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[q], xf, acc, 0, 0, 0);
+                const bf16x8 wf = *(const bf16x8*)(w1s + fr * 144 + q * 32 + fh * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
             }
             const int py = pix / PW, px = pix - py * PW;
             const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
@@ -160,9 +160,10 @@ __global__ __launch_bounds__(512) void res_block_kernel(ResK p) {
             char* dst = ys + pix * 16 + fh * 8;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {              // channels 8q + 4fh .. +3 -> plane q
+                const f32x4 bq = *(const f32x4*)(b1s + 8 * q + 4 * fh);
                 bf16x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(outside ? 0.f : res_act<ACT>(acc[4 * q + i] + b1v[4 * q + i]));
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(outside ? 0.f : res_act<ACT>(acc[4 * q + i] + bq[i]));
                 *(bf16x4*)(dst + q * YPLANE) = o;
             }
         }
@@ -193,32 +194,37 @@ __global__ __launch_bounds__(512) void res_block_kernel(ResK p) {
                 for (int hh = 0; hh < 2; ++hh)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][hh], bfr[t & 1][hh], acc, 0, 0, 0);
             }
-            // bias + leaky, + shortcut (centre pixel of the input patch), -> staging [pixel][64 ch] bf16
+            // bias + leaky, + shortcut (centre pixel of the input patch); the result replaces the shortcut IN PLACE: the
+            // 8 bytes a lane reads are the 8 bytes it writes, no other lane touches them, and the patch row of the centre
+            // pixel (64 channels x 2 B) is exactly an output row - no separate staging tile (18 KB), no barrier in between
             const int pc = (ty + 1) * PW + tx + 1;
-            const char* srow = xs + pc * 128 + fh * 8;
+            char* srow = xs + pc * 128 + fh * 8;
             const int sw = (pc >> 1) & 7;
-            char* dst = stage + (wm * 32 + fr) * ST_ROW + (wn * 32 + 4 * fh) * 2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bf16x4 sc = *(const bf16x4*)(srow + (((wn * 4 + q) ^ sw) << 4));   // channels wn*32 + 8q + 4fh ..
+                char* const sp = srow + (((wn * 4 + q) ^ sw) << 4);                       // channels wn*32 + 8q + 4fh ..
+                const bf16x4 sc = *(const bf16x4*)sp;
+                const f32x4 bq = *(const f32x4*)(b3s + wn * 32 + 8 * q + 4 * fh);
                 bf16x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(res_act<ACT>(acc[4 * q + i] + b3v[4 * q + i]) + (float)sc[i]);
-                *(bf16x4*)(dst + q * 16) = o;
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(res_act<ACT>(acc[4 * q + i] + bq[i]) + (float)sc[i]);
+                *(bf16x4*)sp = o;
             }
         }
-        __syncthreads();                               // staging complete; both patches are free again
+        __syncthreads();                               // the output rows are complete
 
-        if (next < p.ntiles) store_patch(noy0, nox0);
 #pragma unroll
         for (int it = 0; it < (TH * 16 * 8) / NT; ++it) {
             const int idx = tid + it * NT;
             const int pix = idx >> 3, ch = idx & 7;
             const int py = pix >> 4, pxx = pix & 15;
-            const u32x4 v = *(const u32x4*)(stage + pix * ST_ROW + ch * 16);
+            const int pc = (py + 1) * PW + pxx + 1;
+            const u32x4 v = *(const u32x4*)(xs + pc * 128 + ((ch ^ ((pc >> 1) & 7)) << 4));
             *(u32x4*)(p.out + ((((long long)b * p.H + oy0 + py) * p.W + ox0 + pxx) * p.out_ld + p.out_coff) * 2 + ch * 16) = v;
         }
-        __syncthreads();                               // next input patch visible; staging free
+        __syncthreads();                               // every output row has been read: the patch may be replaced
+        if (next < p.ntiles) store_patch(noy0, nox0);
+        __syncthreads();                               // next input patch visible
     }
 }
 
@@ -239,7 +245,7 @@ struct C32K {
 constexpr int kC32Lds = 4 * 192 * 16 + 64 * 592 + 128 * 144;
 
 template <int ACT>
-__global__ __launch_bounds__(512, 2) void conv3x3_c32_pool_kernel(C32K p) {
+__global__ __launch_bounds__(512, 4) void conv3x3_c32_pool_kernel(C32K p) {
     constexpr int NT = 512, TH = 8, PW = 18, NP = 180, NPP = 192;
     constexpr int YPLANE = NPP * 16, YS_BYTES = 4 * YPLANE;
     constexpr int W3_ROW = 592, W3_BYTES = 64 * W3_ROW, ST_ROW = 144;
@@ -430,7 +436,7 @@ int launch_res_block(const ConvLaunch& c1, const ConvLaunch& c3, hipStream_t str
     const long long nt = (long long)k.B * k.tiles_x * k.tiles_y;
     YOLO_REQUIRE(nt < (1ll << 24), YOLO_ERR_SHAPE, "res_block: too many tiles");
     k.ntiles = (int)nt;
-    int grid = 256;                                    // one workgroup per CU (LDS), each walks ntiles / 256 tiles
+    int grid = 512;                                    // two workgroups per CU (75 KB of LDS, <= 128 VGPRs), each walks ntiles / 512 tiles
     if (grid > k.ntiles) grid = k.ntiles;
     static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear
     int dev = 0;
