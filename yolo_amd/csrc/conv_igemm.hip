@@ -1856,6 +1856,12 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
             }
             return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 112: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2, 3>(k, stream);   // 68 with a three-deep ring
+        case 113: case 114:                                                 // 512 x 128 tile, 16 waves of 64 x 64, one workgroup per CU: half the weight stream per MFMA of 61
+            if constexpr (BF16) {
+                if (cfg == 113) return launch_halo<true, 512, 128, 8, 2, true, 16, 0, 4, 2>(k, stream);
+                return launch_halo<true, 512, 128, 8, 2, true, 16, 0, 4, 3>(k, stream);
+            }
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 78: return launch_halo<BF16, 128, 128, 4, 4, true, 16, 0, 1>(k, stream);    // 128 x 128 as 16 waves of 32 x 32 (small-batch slices)
         case 79: return launch_halo<BF16, 128, 128, 4, 4, false, 32, 1, 1>(k, stream);
         case 100: case 101:                                                 // 98 / 99 three K-steps ahead
