@@ -74,6 +74,14 @@ int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream);   // Cin = 
 // conv 3->32 (3x3 s1) + conv 32->64 (3x3 s2) fused, bf16 only (front.hip)
 int launch_front(const ConvLaunch& stem, const ConvLaunch& down, hipStream_t stream);
 // res_block(x, 32): conv 64->32 (1x1) + conv 32->64 (3x3) + shortcut fused, bf16 only (resblock.hip)
+// Stem conv (3 -> 32, K = 27 padded to 32) on two v_mfma_f32_32x32x16_bf16: which im2col tap (ky * 9 + kx * 3 + c, -1 = zero
+// pad) a lane's operand element j of MFMA m holds, for the lane half fh = lane >> 5.  Chosen so that three of the four
+// (m, fh) groups are 8 CONTIGUOUS values of one image row (one 16-byte read in front.hip): rows 0, 1, 2 of the window give
+// their first eight values to (0,0), (1,0), (0,1); the ninth value of each row goes to (1,1).  stem.hip and front.hip use the
+// same assignment, so the fused and the separate kernels add the products in the same order (bit-identical results).
+__host__ __device__ inline int stem_slot_tap(int m, int fh, int j) {
+    return fh == 0 ? (m == 0 ? j : 9 + j) : (m == 0 ? 18 + j : (j < 3 ? 9 * j + 8 : -1));
+}
 int launch_res_block(const ConvLaunch& c1, const ConvLaunch& c3, hipStream_t stream);
 int launch_conv3x3_c32_pool(const ConvLaunch& c3, hipStream_t stream);   // resblock.hip: conv 32->64 3x3 + 2x2 max-pool, bf16
 int launch_maxpool2x2(int dtype, const void* in, int B, int H, int W, int C, void* out, hipStream_t stream);

@@ -33,6 +33,14 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 template <int TH>
 constexpr int front_lds_bytes() { return (((2 * TH + 3) * 108 * 2 + 15) & ~15) + 8 * (2 * TH + 1) * 17 * 16 + 64 * 592 + 96 * 4; }
 
+#ifdef YOLO_CONV_STAMPS
+// diagnostic build: cycles wave 0 of workgroup 0 spends in each phase, summed over its tiles (scripts/front_stamps.py)
+__device__ unsigned long long g_front_stamps[8];
+#define FSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fst_[i] += t_ - ftl_; ftl_ = t_; } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
 struct FrontK {
     const float* img;      // [B,H,W,3] f32
     const u32x4* w0;       // stem weights [32 cout][32 k] bf16, k = (ky*3+kx)*3 + c, BN folded
@@ -84,8 +92,19 @@ __global__ __launch_bounds__(64 * TH, TH == 8 ? 4 : 1) void front_kernel(FrontK 
         const int row = i / 36, ch = i - row * 36;
         *(u32x4*)(w1s + row * W1_ROW + ch * 16) = *(const u32x4*)(p.w1 + (long long)row * p.w1_row + ch * 16);
     }
-    const bf16x8 wf0 = __builtin_bit_cast(bf16x8, p.w0[fr * 4 + fh]);        // A[row = cout fr][k = 8 fh + j]
-    const bf16x8 wf1 = __builtin_bit_cast(bf16x8, p.w0[fr * 4 + 2 + fh]);    //                  k = 16 + 8 fh + j
+    bf16x8 wf0, wf1;                                   // A[row = cout fr][slot (m, fh, j)] = w0[cout][tap] (common.h stem_slot_tap)
+    {
+        const unsigned short* wh = (const unsigned short*)p.w0;
+        u16x8 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t0 = stem_slot_tap(0, fh, j), t1 = stem_slot_tap(1, fh, j);
+            h0[j] = t0 >= 0 ? wh[fr * 32 + t0] : (unsigned short)0;
+            h1[j] = t1 >= 0 ? wh[fr * 32 + t1] : (unsigned short)0;
+        }
+        wf0 = __builtin_bit_cast(bf16x8, h0);
+        wf1 = __builtin_bit_cast(bf16x8, h1);
+    }
     if (tid < 32) bias[tid] = p.b0[tid];
     else if (tid < 96) bias[tid] = p.b1[tid - 32];
     const int wm = wave >> 1, wn = wave & 1;           // conv phase: wave tile = 32 pixels (2 tile rows) x 32 channels
@@ -93,16 +112,10 @@ __global__ __launch_bounds__(64 * TH, TH == 8 ? 4 : 1) void front_kernel(FrontK 
     // LDS where they are used (keeping 32 of them in registers cost the second workgroup per CU)
     const f32x4* const b0p = (const f32x4*)(bias + 4 * fh);
     const f32x4* const b1p = (const f32x4*)(bias + 32 + wn * 32 + 4 * fh);
-    // stem gather tables: this lane's 16 im2col taps k = 16 m + 8 fh + j as float offsets inside the image patch
-    int koff[2][8];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kq = 16 * m + 8 * fh + j;
-            const int ky = kq / 9;
-            koff[m][j] = kq < 27 ? ky * IWP + (kq - ky * 9) : 0;      // k >= 27: any finite value (its weight is 0)
-        }
+    // stem gather (stem_slot_tap): lanes fh = 0 take the first eight values of window rows 0 and 1, lanes fh = 1 those of row 2 and
+    // the ninth value of each row; a row's nine values are contiguous bf16 in the image patch, so eight of them are ONE 16-byte LDS
+    // read at a 2-byte-aligned address (gfx950 reads LDS unaligned) instead of eight ds_read_u16 + packing
+    struct __attribute__((packed, aligned(2))) Run8 { u16x8 v; };
 
     const int per_img = p.tiles_x * p.tiles_y;
     const float inv_per_img = 1.0f / (float)per_img, inv_tx = 1.0f / (float)p.tiles_x;
@@ -169,6 +182,10 @@ __global__ __launch_bounds__(64 * TH, TH == 8 ? 4 : 1) void front_kernel(FrontK 
     }
     __syncthreads();
 
+#ifdef YOLO_CONV_STAMPS
+    unsigned long long fst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ftl_ = __builtin_amdgcn_s_memtime();
+#endif
     for (; tile < p.ntiles; tile += gridDim.x) {
         const int b = nb, oy0 = noy0, ox0 = nox0;
         const int next = tile + gridDim.x;
@@ -176,41 +193,68 @@ __global__ __launch_bounds__(64 * TH, TH == 8 ? 4 : 1) void front_kernel(FrontK 
             tile_origin(next, nb, noy0, nox0);
             load_image_patch(nb, noy0, nox0);          // in flight during the two compute phases
         }
+        FSTAMP(0);                                     // next patch: addresses + load issue
 
-        // ---- stem: groups of 32 stem pixels --------------------------------------------------------------
-        for (int g = wave; g < NG; g += NW) {
-            // gather side: pixel = lane & 31
-            const bool pv = g < SH || fr < SH;
-            const int sy = g < SH ? g : (pv ? fr : 0);       // lanes past the column group read row 0, unused
-            const int sx = g < SH ? fr : 32;
-            const unsigned short* base = img + sy * IWP + sx * 3;
-            u16x8 g0, g1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                g0[j] = base[koff[0][j]];
-                g1[j] = base[koff[1][j]];
-            }
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, g0), a1 = __builtin_bit_cast(bf16x8, g1);
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, a0, acc, 0, 0, 0);     // rows = channels, cols = pixels
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, a1, acc, 0, 0, 0);
-            // stem pixels outside the image are the stride-2 conv's zero padding (only row/column -1 can occur)
-            const bool outside = (oy0 == 0 && sy == 0) || (ox0 == 0 && sx == 0);
-            if (pv) {
-                char* dst = stem + (((sx & 1) * SH + sy) * SWH + (sx >> 1)) * 16 + fh * 8;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {          // channels 8q + 4fh .. +3 -> chunk q, bytes fh*8..
-                    const f32x4 bq = b0p[2 * q];
-                    bf16x4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(outside ? 0.f : act<ACT>(acc[4 * q + i] + bq[i]));
-                    *(bf16x4*)(dst + q * 2 * PLANE) = o;
+        // ---- stem: groups of 32 stem pixels; a wave takes its first two groups together (two independent read -> MFMA ->
+        // activation -> write chains in flight instead of one), waves 0 and 1 then a third ----------------------------
+        {
+            auto gather = [&](int g, bf16x8& a0, bf16x8& a1, int& sy, int& sx, bool& pv) {
+                pv = g < SH || fr < SH;                          // gather side: pixel = lane & 31
+                sy = g < SH ? g : (pv ? fr : 0);                 // lanes past the column group read row 0, unused
+                sx = g < SH ? fr : 32;
+                const unsigned short* base = img + sy * IWP + sx * 3;
+                const u16x8 g0 = ((const Run8*)(base + (fh ? 2 * IWP : 0)))->v;
+                u16x8 g1;
+                if (fh == 0) {
+                    g1 = ((const Run8*)(base + IWP))->v;
+                } else {
+                    g1 = u16x8{base[8], base[IWP + 8], base[2 * IWP + 8], 0, 0, 0, 0, 0};
                 }
+                a0 = __builtin_bit_cast(bf16x8, g0);
+                a1 = __builtin_bit_cast(bf16x8, g1);
+            };
+            auto finish = [&](const f32x16& acc, int sy, int sx, bool pv) {
+                // stem pixels outside the image are the stride-2 conv's zero padding (only row/column -1 can occur)
+                const bool outside = (oy0 == 0 && sy == 0) || (ox0 == 0 && sx == 0);
+                if (pv) {
+                    char* dst = stem + (((sx & 1) * SH + sy) * SWH + (sx >> 1)) * 16 + fh * 8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {          // channels 8q + 4fh .. +3 -> chunk q, bytes fh*8..
+                        const f32x4 bq = b0p[2 * q];
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(outside ? 0.f : act<ACT>(acc[4 * q + i] + bq[i]));
+                        *(bf16x4*)(dst + q * 2 * PLANE) = o;
+                    }
+                }
+            };
+            static_assert(NG > NW && NG <= 3 * NW, "every wave has two groups, some a third");
+            bf16x8 a0, a1, c0, c1;
+            int sya, sxa, syc, sxc;
+            bool pva, pvc;
+            gather(wave, a0, a1, sya, sxa, pva);
+            gather(wave + NW, c0, c1, syc, sxc, pvc);
+            f32x16 acca, accc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accc[r] = 0.f; }
+            acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, a0, acca, 0, 0, 0);     // rows = channels, cols = pixels
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, c0, accc, 0, 0, 0);
+            acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, a1, acca, 0, 0, 0);
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, c1, accc, 0, 0, 0);
+            finish(acca, sya, sxa, pva);
+            finish(accc, syc, sxc, pvc);
+            if (wave + 2 * NW < NG) {                            // wave-uniform
+                gather(wave + 2 * NW, a0, a1, sya, sxa, pva);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acca[r] = 0.f;
+                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, a0, acca, 0, 0, 0);
+                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, a1, acca, 0, 0, 0);
+                finish(acca, sya, sxa, pva);
             }
         }
+        FSTAMP(1);                                     // stem groups of this wave
         __syncthreads();
+        FSTAMP(2);                                     // barrier after the stem
 
         // ---- stride-2 conv out of the stem patch: A = weights (32 couts of this wave), B = 32 pixels ----------
         {
@@ -248,12 +292,15 @@ __global__ __launch_bounds__(64 * TH, TH == 8 ? 4 : 1) void front_kernel(FrontK 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[q][i] = (__bf16)act<ACT>(acc[4 * q + i] + bq[i]);
             }
+            FSTAMP(3);                                 // conv MFMAs + activation
             __syncthreads();
+            FSTAMP(4);                                 // barrier before staging
             char* dst = stage + (wm * 32 + fr) * ST_ROW + (wn * 32 + 4 * fh) * 2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) *(bf16x4*)(dst + q * 16) = o[q];
         }
         __syncthreads();                               // staging complete; the image patch is free again
+        FSTAMP(5);                                     // staging writes + barrier
 
         if (next < p.ntiles) store_image_patch(noy0, nox0);
         // ---- stores: 8 x 16 B per pixel, pixels of a tile row contiguous in memory ----------------------------
@@ -265,9 +312,23 @@ __global__ __launch_bounds__(64 * TH, TH == 8 ? 4 : 1) void front_kernel(FrontK 
             const u32x4 v = *(const u32x4*)(stage + pix * ST_ROW + ch * 16);
             *(u32x4*)(p.out + ((((long long)b * Ho + oy0 + py) * Wo + ox0 + pxx) * p.out_ld + p.out_coff) * 2 + ch * 16) = v;
         }
+        FSTAMP(6);                                     // image patch -> LDS (waits for its loads), output stores
         __syncthreads();                               // next image patch visible; staging (= stem patch) free
+        FSTAMP(7);                                     // last barrier
     }
+#ifdef YOLO_CONV_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) g_front_stamps[i] = fst_[i];
+#endif
 }
+
+#ifdef YOLO_CONV_STAMPS
+extern "C" int yolo_debug_read_front_stamps(unsigned long long* host) {
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_front_stamps)) != hipSuccess) return YOLO_ERR_HIP;
+    return hipMemcpy(host, dptr, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost) == hipSuccess ? YOLO_OK : YOLO_ERR_HIP;
+}
+#endif
 
 template <int TH>
 static int launch_front_th(const FrontK& k, int grid, int act_mode, hipStream_t stream) {

@@ -91,9 +91,21 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     float* tl = tile[wave];
-    // weight fragments: B[k = 16m + 8h + j][cout = fr]  <-  w[cout][k]
-    const bf16x8 wf0 = __builtin_bit_cast(bf16x8, w[fr * 4 + fh]);
-    const bf16x8 wf1 = __builtin_bit_cast(bf16x8, w[fr * 4 + 2 + fh]);
+    // weight fragments: B[slot (m, fh, j)][cout = fr]  <-  w[cout][tap] (common.h stem_slot_tap)
+    bf16x8 wf0, wf1;
+    {
+        const unsigned short* wh = (const unsigned short*)w;
+        typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+        u16x8 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t0 = stem_slot_tap(0, fh, j), t1 = stem_slot_tap(1, fh, j);
+            h0[j] = t0 >= 0 ? wh[fr * 32 + t0] : (unsigned short)0;
+            h1[j] = t1 >= 0 ? wh[fr * 32 + t1] : (unsigned short)0;
+        }
+        wf0 = __builtin_bit_cast(bf16x8, h0);
+        wf1 = __builtin_bit_cast(bf16x8, h1);
+    }
     // per-lane im2col tables (invariant over pixels)
     int koff[2][8];
     unsigned need[2][8];
@@ -101,10 +113,11 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int kq = 16 * m + 8 * fh + j;
+            const int tap = stem_slot_tap(m, fh, j);
+            const int kq = tap < 0 ? 0 : tap;
             const int ky = kq / 9, rem = kq - ky * 9, kx = rem / 3;
             koff[m][j] = (ky - 1) * W * 3 + rem - 3;
-            need[m][j] = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u) | (kq >= 27 ? 16u : 0u);
+            need[m][j] = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u) | (tap < 0 ? 16u : 0u);
         }
     const float bv = bias[fr];
     const long long npix = (long long)B * H * W;
