@@ -107,7 +107,7 @@ def test_build_networks_bf16_vs_oracle(v2_bf16, v2_params, O2):
 
 
 def test_stem_pool_fusion_equals_separate_kernels(v2_bf16):
-    """bf16 plan: the stem conv and the max-pool behind it run as one kernel (stem.hip POOL), and so do the second conv
+    """bf16 plan: the stem conv and the max-pool behind it run as one kernel (front.hip stem_pool_kernel), and so do the second conv
     (32 -> 64) and its pool (resblock.hip conv3x3_c32_pool_kernel); YOLO_NO_STEM_POOL_FUSION=1 keeps all four apart.  The pool of the bf16-rounded activations equals the rounded pool of the f32 ones (rounding is
     monotonic), so the logits agree bit for bit; also on a rectangular input and with lanes."""
     import os

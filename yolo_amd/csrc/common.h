@@ -59,7 +59,6 @@ struct ConvLaunch {
     int small_plan;        // 1: the launcher may split K
     void* scratch;         // >= S * M * Cout * 4 bytes when small_plan
     size_t scratch_bytes;
-    int pool2x2;           // stem only (bf16): the output is the 2x2 / stride-2 max-pool of the conv's output (yolo_v2.py:34-35 fused)
 };
 
 // Measurement aid: when `record_kernel_names` is set (only yolo_net_forward_timed sets it), every launcher
@@ -83,6 +82,7 @@ __host__ __device__ inline int stem_slot_tap(int m, int fh, int j) {
     return fh == 0 ? (m == 0 ? j : 9 + j) : (m == 0 ? 18 + j : (j < 3 ? 9 * j + 8 : -1));
 }
 int launch_res_block(const ConvLaunch& c1, const ConvLaunch& c3, hipStream_t stream);
+int launch_stem_pool(const ConvLaunch& c0, hipStream_t stream);          // front.hip: stem conv + 2x2 max-pool out of an LDS image patch, bf16
 int launch_conv3x3_c32_pool(const ConvLaunch& c3, hipStream_t stream);   // resblock.hip: conv 32->64 3x3 + 2x2 max-pool, bf16
 int launch_maxpool2x2(int dtype, const void* in, int B, int H, int W, int C, void* out, hipStream_t stream);
 int launch_cast_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t stream);

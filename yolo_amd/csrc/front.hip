@@ -330,6 +330,204 @@ extern "C" int yolo_debug_read_front_stamps(unsigned long long* host) {
 }
 #endif
 
+// ---- stem conv 3 -> 32 + BN + leaky + 2x2 max-pool (YOLOv2's first conv + pool, yolo_v2.py:34-35; bf16) out of an LDS image patch ----
+// The stem phase of front_kernel with the pool taken in registers.  One workgroup of 8 waves walks over tiles of 8 x 16 POOLED
+// pixels = 16 x 32 stem pixels = 16 groups of 32: wave w computes stem rows 2w and 2w + 1 of the tile (two independent gather ->
+// MFMA -> activation chains), takes the maximum of the two rows in registers and of horizontally adjacent pixels through a lane
+// exchange, and the even lanes store 4 x 4 channels of one pooled pixel each.  The pool sees the bf16-rounded activations, like the
+// separate max-pool kernel (bit-identical).  LDS: the 18 x 34 x 3 image patch in bf16 (3.9 KB) + 32 biases; no staging.
+struct StemPoolK {
+    const float* img;      // [B,H,W,3] f32
+    const u32x4* w0;       // stem weights [32 cout][32 k] bf16, k = (ky*3+kx)*3 + c, BN folded
+    const float* b0;       // [32]
+    char* out;             // [B,H/2,W/2,out_ld] bf16 (+ out_coff channels)
+    int B, H, W, out_ld, out_coff;
+    int tiles_x, tiles_y, ntiles;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(512, 4) void stem_pool_kernel(StemPoolK p) {
+    constexpr int NT = 512;
+    constexpr int IH = 18, IROW = 102, IWP = 108;      // image patch: 18 x 34 pixels x 3 values, rows padded to 108
+    constexpr int NE = (IH * IROW + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) unsigned short img[IH * IWP + 8];
+    __shared__ __attribute__((aligned(16))) float bias[32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+
+    bf16x8 wf0, wf1;                                   // A[row = cout fr][slot (m, fh, j)] = w0[cout][tap] (common.h stem_slot_tap)
+    {
+        const unsigned short* wh = (const unsigned short*)p.w0;
+        u16x8 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t0 = stem_slot_tap(0, fh, j), t1 = stem_slot_tap(1, fh, j);
+            h0[j] = t0 >= 0 ? wh[fr * 32 + t0] : (unsigned short)0;
+            h1[j] = t1 >= 0 ? wh[fr * 32 + t1] : (unsigned short)0;
+        }
+        wf0 = __builtin_bit_cast(bf16x8, h0);
+        wf1 = __builtin_bit_cast(bf16x8, h1);
+    }
+    if (tid < 32) bias[tid] = p.b0[tid];
+    const f32x4* const b0p = (const f32x4*)(bias + 4 * fh);
+    struct __attribute__((packed, aligned(2))) Run8 { u16x8 v; };
+
+    const int per_img = p.tiles_x * p.tiles_y;
+    const float inv_per_img = 1.0f / (float)per_img, inv_tx = 1.0f / (float)p.tiles_x;
+    auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {     // tile < 2^24: float quotient + fix-up
+        b = (int)((float)tile * inv_per_img);
+        int r = tile - b * per_img;
+        if (r < 0) { --b; r += per_img; } else if (r >= per_img) { ++b; r -= per_img; }
+        int ty = (int)((float)r * inv_tx);
+        int tx = r - ty * p.tiles_x;
+        if (tx < 0) { --ty; tx += p.tiles_x; } else if (tx >= p.tiles_x) { ++ty; tx -= p.tiles_x; }
+        oy0 = ty * 8;
+        ox0 = tx * 16;
+    };
+    float pre[NE];
+    int lidx[NE], goff[NE], ipos[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int idx = tid + e * NT;
+        const bool v = idx < IH * IROW;
+        const int iy = v ? idx / IROW : 0;
+        const int rx = v ? idx - iy * IROW : 0;
+        lidx[e] = v ? iy * IWP + rx : -1;
+        goff[e] = iy * p.W * 3 + rx;
+        ipos[e] = iy | ((rx / 3) << 8) | ((rx % 3) << 16);
+    }
+    auto load_image_patch = [&](int b, int oy0, int ox0) {      // global -> registers
+        const int gy0 = 2 * oy0 - 1, gx0 = 2 * ox0 - 1;
+        const bool interior = gy0 >= 0 && gy0 + IH <= p.H && gx0 >= 0 && gx0 + 34 <= p.W;      // wave-uniform
+        if (interior) {
+            const float* org = p.img + (((long long)b * p.H + gy0) * p.W + gx0) * 3;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) pre[e] = org[lidx[e] >= 0 ? goff[e] : 0];
+        } else {                                                  // out-of-image elements read a clamped pixel
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                int gy = gy0 + (ipos[e] & 255), gx = gx0 + ((ipos[e] >> 8) & 255);
+                gy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+                pre[e] = p.img[(((long long)b * p.H + gy) * p.W + gx) * 3 + (ipos[e] >> 16)];
+            }
+        }
+    };
+    auto store_image_patch = [&](int oy0, int ox0) {             // registers -> LDS, zeros outside the image (SAME padding)
+        const int gy0 = 2 * oy0 - 1, gx0 = 2 * ox0 - 1;
+        const bool interior = gy0 >= 0 && gy0 + IH <= p.H && gx0 >= 0 && gx0 + 34 <= p.W;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            bool inside = true;
+            if (!interior) {
+                const int gy = gy0 + (ipos[e] & 255), gx = gx0 + ((ipos[e] >> 8) & 255);
+                inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            }
+            if (lidx[e] >= 0) img[lidx[e]] = __builtin_bit_cast(unsigned short, (__bf16)(inside ? pre[e] : 0.f));
+        }
+    };
+
+    int tile = blockIdx.x;
+    int nb = 0, noy0 = 0, nox0 = 0;
+    if (tile < p.ntiles) {
+        tile_origin(tile, nb, noy0, nox0);
+        load_image_patch(nb, noy0, nox0);
+        store_image_patch(noy0, nox0);
+    }
+    __syncthreads();
+
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        const int b = nb, oy0 = noy0, ox0 = nox0;
+        const int next = tile + gridDim.x;
+        if (next < p.ntiles) {
+            tile_origin(next, nb, noy0, nox0);
+            load_image_patch(nb, noy0, nox0);          // in flight during the compute phase
+        }
+        // stem rows 2 wave and 2 wave + 1 of the tile, pixel fr of the row: window origin = image patch (row, 3 fr)
+        float va[16];
+        {
+            auto gather = [&](int sy, bf16x8& a0, bf16x8& a1) {
+                const unsigned short* base = img + sy * IWP + fr * 3;
+                const u16x8 g0 = ((const Run8*)(base + (fh ? 2 * IWP : 0)))->v;
+                u16x8 g1;
+                if (fh == 0) {
+                    g1 = ((const Run8*)(base + IWP))->v;
+                } else {
+                    g1 = u16x8{base[8], base[IWP + 8], base[2 * IWP + 8], 0, 0, 0, 0, 0};
+                }
+                a0 = __builtin_bit_cast(bf16x8, g0);
+                a1 = __builtin_bit_cast(bf16x8, g1);
+            };
+            bf16x8 a0, a1, c0, c1;
+            gather(2 * wave, a0, a1);
+            gather(2 * wave + 1, c0, c1);
+            f32x16 acca, accc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accc[r] = 0.f; }
+            acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, a0, acca, 0, 0, 0);     // rows = channels, cols = pixels
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, c0, accc, 0, 0, 0);
+            acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, a1, acca, 0, 0, 0);
+            accc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, c1, accc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {              // register 4 q + i = channel 8 q + 4 fh + i
+                const f32x4 bq = b0p[2 * q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x0 = (float)(__bf16)act<ACT>(acca[4 * q + i] + bq[i]);
+                    const float x1 = (float)(__bf16)act<ACT>(accc[4 * q + i] + bq[i]);
+                    va[4 * q + i] = __builtin_fmaxf(x0, x1);                            // the two rows of the window
+                }
+            }
+        }
+        // the two columns of the window: lanes fr and fr ^ 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, va[r]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            va[r] = __builtin_fmaxf(va[r], o);
+        }
+        if ((fr & 1) == 0) {
+            char* op = p.out + ((((long long)b * Ho + oy0 + wave) * Wo + ox0 + (fr >> 1)) * p.out_ld + p.out_coff + 4 * fh) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)va[4 * q + i];
+                *(bf16x4*)(op + q * 16) = o;
+            }
+        }
+        __syncthreads();                               // every wave has read the image patch
+        if (next < p.ntiles) store_image_patch(noy0, nox0);
+        __syncthreads();                               // next image patch visible
+    }
+}
+
+// images [B,H,W,3] f32 -> out [B,H/2,W/2,32] bf16 = pooling_layer(conv_layer(x, 32, 3)) (yolo_v2.py:34-35).  c0: the conv's launch
+// description with `out` / `out_ld` / `out_coff` describing the POOLED tensor.
+int launch_stem_pool(const ConvLaunch& c0, hipStream_t stream) {
+    YOLO_REQUIRE(c0.Cin == 3 && c0.Cout == 32 && c0.ksize == 3 && c0.stride == 1 && c0.in_ld == 3 && c0.in_coff == 0 &&
+                 (c0.leaky == 1 || c0.leaky == 2), YOLO_ERR_UNSUPPORTED, "stem + pool: only 3->32 (3x3 s1) is implemented");
+    YOLO_REQUIRE(c0.H % 16 == 0 && c0.W % 32 == 0 && c0.out_ld % 4 == 0 && c0.out_coff % 4 == 0, YOLO_ERR_SHAPE,
+                 "stem + pool: H must be a multiple of 16, W of 32");
+    StemPoolK k;
+    k.img = (const float*)c0.in; k.w0 = (const u32x4*)c0.w; k.b0 = c0.bias; k.out = (char*)c0.out;
+    k.B = c0.B; k.H = c0.H; k.W = c0.W; k.out_ld = c0.out_ld; k.out_coff = c0.out_coff;
+    k.tiles_x = (c0.W / 2) / 16; k.tiles_y = (c0.H / 2) / 8;
+    const long long nt = (long long)k.B * k.tiles_x * k.tiles_y;
+    YOLO_REQUIRE(nt < (1ll << 24), YOLO_ERR_SHAPE, "stem + pool: too many tiles");
+    k.ntiles = (int)nt;
+    int grid = 512;                                    // two workgroups of eight waves per CU (<= 128 VGPRs)
+    if (grid > k.ntiles) grid = k.ntiles;
+    note_kernel("yolo::stem_pool_kernel<%d>", c0.leaky);
+    if (c0.leaky == 1) hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(grid), dim3(512), 0, stream, k);
+    else hipLaunchKernelGGL(stem_pool_kernel<2>, dim3(grid), dim3(512), 0, stream, k);
+    YOLO_HIP_CHECK(hipGetLastError());
+    return YOLO_OK;
+}
+
 template <int TH>
 static int launch_front_th(const FrontK& k, int grid, int act_mode, hipStream_t stream) {
     static std::atomic<bool> attr_done[16];   // zero-initialised; setting the attribute twice is harmless, the flag only must not tear

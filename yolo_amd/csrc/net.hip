@@ -585,7 +585,7 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
     ConvLaunch front_p, res_p;
     memset(&front_p, 0, sizeof(front_p));
     memset(&res_p, 0, sizeof(res_p));
-    // bf16 YOLOv2: the stem conv and the max-pool behind it run as ONE kernel (stem.hip POOL) when the pool is the stem
+    // bf16 YOLOv2: the stem conv and the max-pool behind it run as ONE kernel (front.hip stem_pool_kernel) when the pool is the stem
     // output's only reader (YOLO_NO_STEM_POOL_FUSION=1 keeps them apart, for A/B measurements and the equality test)
     const char* np_env = getenv("YOLO_NO_STEM_POOL_FUSION");
     const bool fuse_stem_pool = net->dtype == YOLO_DTYPE_BF16 && !(np_env && atoi(np_env) != 0);
@@ -634,7 +634,8 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
                 }
             }
         }
-        if (fuse_stem_pool && L.stem && st.out >= 0 && st.res < 0 && p.H % 2 == 0 && p.W % 16 == 0) {
+        bool stem_pool = false;
+        if (fuse_stem_pool && L.stem && st.out >= 0 && st.res < 0 && p.H % 16 == 0 && p.W % 32 == 0) {
             const size_t si = (size_t)(&st - P->steps.data());
             if (si + 1 < P->steps.size() && P->steps[si + 1].layer < 0 && P->steps[si + 1].in == st.out) {
                 int readers = 0;
@@ -642,7 +643,7 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
                 if (readers == 1) {
                     const Tens& to = P->tens[P->steps[si + 1].out];
                     p.out = (char*)workspace + to.offset; p.out_ld = to.ld; p.out_coff = 0;
-                    p.pool2x2 = 1;
+                    stem_pool = true;
                     skip_pool = true;
                 }
             }
@@ -718,6 +719,9 @@ static int forward_impl(YoloNet* net, const float* images, int B, int H, int W, 
         if (c32_pool) {
             fill_conv(L, p);
             rc = launch_conv3x3_c32_pool(p, (hipStream_t)stream);
+        } else if (stem_pool) {
+            fill_conv(L, p);
+            rc = launch_stem_pool(p, (hipStream_t)stream);
         } else {
             rc = run_conv(L, p, (hipStream_t)stream);
         }

@@ -77,13 +77,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
 // every lane stores 32 contiguous bytes (16 channels of one pixel): 2 KiB contiguous per wave.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
-// POOL: conv + pooling_layer fused (yolo_v2.py:34-35): a wave's 32 pixels are a 2 x 16 block instead of 32 in a row, the
-// epilogue takes the maximum over each 2 x 2 window of the bf16-rounded activations (rounding is monotonic, so this equals the
-// pool of the rounded tensor bit for bit) and writes the [B, H/2, W/2, 32] tensor: the full-resolution map (709 MB at batch 64)
-// is never written or read.
-template <bool POOL>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in, const u32x4* __restrict__ w,
                                                         const float* __restrict__ bias, char* __restrict__ out,
                                                         int B, int H, int W, int out_ld, int out_coff, int leaky) {
@@ -121,17 +115,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         }
     const float bv = bias[fr];
     const long long npix = (long long)B * H * W;
-    const int gpr = W >> 4;                            // POOL: 2 x 16 blocks per row pair (W % 16 == 0, H % 2 == 0)
-    const long long ngroups = POOL ? (long long)B * (H >> 1) * gpr : (npix + 31) >> 5;
+    const long long ngroups = (npix + 31) >> 5;
     for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long long)gridDim.x * 4) {
-        long long m;
-        if constexpr (POOL) {
-            const long long rowpair = grp / gpr;       // = b * (H / 2) + y / 2
-            const int gx = (int)(grp - rowpair * gpr);
-            m = (rowpair * 2 + (fr >> 4)) * W + gx * 16 + (fr & 15);
-        } else {
-            m = grp * 32 + fr;
-        }
+        const long long m = grp * 32 + fr;
         const bool pv = m < npix;
         const int x = (int)(m % W);
         const int y = (int)((m / W) % H);
@@ -157,21 +143,6 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             if (leaky == 1) v = leaky_v3(v);
             else if (leaky == 2) v = __builtin_fmaxf(0.1f * v, v);
             tl[row * 33 + fr] = v;
-        }
-        if constexpr (POOL) {                          // lane: pooled pixel lane >> 3 of the block's 8, channels 4 (lane & 7) ..
-            const int pj = lane >> 3, c4 = (lane & 7) * 4;
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v0 = (float)(__bf16)tl[(2 * pj) * 33 + c4 + e], v1 = (float)(__bf16)tl[(2 * pj + 1) * 33 + c4 + e];
-                const float v2 = (float)(__bf16)tl[(16 + 2 * pj) * 33 + c4 + e], v3 = (float)(__bf16)tl[(17 + 2 * pj) * 33 + c4 + e];
-                o[e] = (__bf16)__builtin_fmaxf(__builtin_fmaxf(v0, v1), __builtin_fmaxf(v2, v3));
-            }
-            const long long rowpair = grp / gpr;
-            const int gx = (int)(grp - rowpair * gpr);
-            const long long mo = rowpair * (W >> 1) + gx * 8 + pj;
-            *(bf16x4*)(out + (mo * out_ld + out_coff + c4) * 2) = o;
-            continue;
         }
         const int pr = lane >> 1, c0 = (lane & 1) * 16;
         const long long mo = grp * 32 + pr;
@@ -199,18 +170,10 @@ int launch_stem(int dtype, const ConvLaunch& p, hipStream_t stream) {
         const long long ngroups = (npix + 31) / 32;
         long long g = (ngroups + 3) / 4;
         if (g > 256 * 16) g = 256 * 16;
-        if (p.pool2x2) {
-            YOLO_REQUIRE(p.H % 2 == 0 && p.W % 16 == 0, YOLO_ERR_SHAPE, "stem + pool: H must be even and W a multiple of 16");
-            note_kernel("yolo::stem_mfma_kernel<true>");
-            hipLaunchKernelGGL(stem_mfma_kernel<true>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.in,
-                               (const u32x4*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
-        } else {
-            note_kernel("yolo::stem_mfma_kernel<false>");
-            hipLaunchKernelGGL(stem_mfma_kernel<false>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.in,
-                               (const u32x4*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
-        }
+        note_kernel("yolo::stem_mfma_kernel");
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float*)p.in,
+                           (const u32x4*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
     } else {
-        YOLO_REQUIRE(!p.pool2x2, YOLO_ERR_UNSUPPORTED, "stem + pool: bf16 only");
         note_kernel("yolo::stem_kernel<false, 32>");
         hipLaunchKernelGGL((stem_kernel<false, 32>), dim3(grid), dim3(256), 0, stream, (const float*)p.in,
                            (const float*)p.w, p.bias, (char*)p.out, p.B, p.H, p.W, p.out_ld, p.out_coff, p.leaky);
