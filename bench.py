@@ -262,7 +262,7 @@ def main():
     dt, out = timed(lambda: net.detect(images, 50, 0.5, 0.5), args.steps, args.warmup, spread=step_ms)
     ndet = int(out[4].sum().item())
     work = B * S * S // (416 * 416)                        # the library's rule (net.hip lane_count), including the clamps
-    lanes = int(os.environ.get("YOLO_LANES", "0")) or (3 if work >= 56 else 2 if work >= 26 else 1)
+    lanes = int(os.environ.get("YOLO_LANES", "0")) or (2 if work >= 90 else 3 if work >= 56 else 2 if work >= 26 else 1)
     lanes = max(1, min(lanes, 8, B))
 
     roofline, layer_ms, info, flops, kernels = dominant_kernel(net, images, args.dtype, B, S, lanes)

@@ -54,7 +54,7 @@ int yolo_net_destroy(YoloNet* net);
 size_t yolo_net_workspace_bytes(const YoloNet* net, int B, int H, int W);
 /* images [B,H,W,3] f32 -> fm1 [B,H/32,W/32,3*(5+C)], fm2 [B,H/16,W/16,.], fm3 [B,H/8,W/8,.] f32.
  * Ordered on `stream` like a single launch.  By the work of the call in 416 x 416 images (B * H * W / 416^2): from 26 up the
- * images run as two, from 56 up as three sub-batches ("lanes"), one on `stream` and the others on streams the handle owns,
+ * images run as two, from 56 to 89 as three, from 90 up as two again sub-batches ("lanes"), one on `stream` and the others on streams the handle owns,
  * forked and joined with events; the result does not depend on the split.  YOLO_LANES=<1..8> in the environment overrides
  * the lane count (1: none; never more lanes than images).
  * One forward at a time per handle: concurrent calls on one handle would share its side streams and plans. */

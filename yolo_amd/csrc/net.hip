@@ -527,7 +527,8 @@ extern "C" int yolo_net_num_layers(const YoloNet* net) { return net ? (int)net->
 // GPU: the partly filled last round of workgroups of one launch (e.g. 676 tiles on 512 slots) and the drain / fill
 // between dependent launches are covered by the other lane's kernels.  Results do not depend on the split: every
 // output element is accumulated in the same order whatever tile or batch it is part of.
-// Default, by the work of the call in 416 x 416 images (B * H * W / 416^2): 2 lanes from 26 up, 3 from 56 up (round-3 kernels,
+// Default, by the work of the call in 416 x 416 images (B * H * W / 416^2): 2 lanes from 26 up, 3 from 56 to 89, 2 again from 90 up
+// (batch 72: 5.31 / 5.34 ms for 2 / 3 lanes, 80: 5.96 / 5.89, 88: 6.53 / 6.54, 96: 7.05 / 7.17, 128: 9.44 / 9.56, 160: 11.8 / 12.2; round-3 kernels,
 // one MI355X, ms per detect call for 1 / 2 / 3 lanes: batch 16 2.17 / 2.21; 20 2.26 / 2.32 / 2.44; 24 2.40 / 2.45 / 2.59;
 // 28 2.98 / 2.75 / 2.74; 40 3.47 / 3.28 / 3.32; 48 3.76 / 3.64 / 3.73; 56 4.73 / 4.29 / 4.20; 608 x 608 batch 8 (work 17) 2.33 / 2.44).
 // YOLO_LANES=<n> in the environment (read per call) sets the number of lanes; 1 = one launch per layer for the whole batch.
@@ -535,7 +536,7 @@ constexpr int MAX_LANES = 8;
 static int lane_count(int B, int H, int W) {
     const char* e = getenv("YOLO_LANES");
     const long long work = (long long)B * H * W / (416 * 416);
-    int n = e ? atoi(e) : (work >= 56 ? 3 : work >= 26 ? 2 : 1);
+    int n = e ? atoi(e) : (work >= 90 ? 2 : work >= 56 ? 3 : work >= 26 ? 2 : 1);
     if (n < 1) n = 1;
     if (n > MAX_LANES) n = MAX_LANES;
     return n < B ? n : B;
