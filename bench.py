@@ -172,8 +172,8 @@ def dominant_kernel(net, images, dtype, B, S, lanes, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
