@@ -124,6 +124,25 @@ def test_stem_pool_fusion_equals_separate_kernels(v2_bf16):
         assert torch.equal(fused, apart), float((fused - apart).abs().max())
 
 
+def test_small_batch_plan(v2_bf16, v2_stream):
+    """yolo_v2(False, dtype="bf16", small_batch_plan=True): the split-K plan of yolo_net_set_small_batch_plan applies to this net
+    too; at batch 1 and 2 it stays within the whole-stack bf16 tolerance of the default plan, is deterministic, and does apply."""
+    from conftest import rel_rms_ok
+    from yolo_amd.yolo_v2.yolo.yolo_v2 import yolo_v2
+    split = yolo_v2(False, dtype="bf16", small_batch_plan=True).load_variables(v2_stream)
+    for B, H, W in ((1, 416, 416), (2, 160, 96)):
+        x = np.random.default_rng(B).random((B, H, W, 3), dtype=np.float32) * 2 - 1
+        b = v2_bf16.build_networks(x).cpu().numpy()
+        a = split.build_networks(x).cpu().numpy()
+        a2 = split.build_networks(x).cpu().numpy()
+        assert np.array_equal(a, a2)
+        ok, maxerr, rms = rel_rms_ok(a, b, 1e-1)
+        rmserr = float(np.sqrt(np.mean((a - b) ** 2)))
+        assert ok, (maxerr, rms)
+        assert rmserr <= 3e-2 * rms, (rmserr, rms)
+        assert rmserr > 0, "the plan did not apply: outputs are bit-identical to the default plan"
+
+
 def test_layerwise_composition_equals_fused_plan(v2_f32, O2):
     """build_networks written with the layer-level drop-ins (the reference's own structure, yolo_v2.py:34-68)
     gives the fused plan's logits."""

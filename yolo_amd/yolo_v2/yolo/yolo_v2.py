@@ -78,7 +78,7 @@ def darknet_stream_to_variables(stream, num_class=len(cfg.CLASSES), box_per_cell
 
 class yolo_v2(object):
 
-    def __init__(self, isTraining=True, dtype="fp32"):
+    def __init__(self, isTraining=True, dtype="fp32", small_batch_plan=False):
         # yolo_v2.py:8-16.  The reference defaults to isTraining=True and its inference callers pass False
         # (test_val.py:167); the training graph (labels / loss_layer) is not part of this build.
         if isTraining:
@@ -93,6 +93,7 @@ class yolo_v2(object):
         self.alpha = cfg.ALPHA
         self.dtype = dtype
         self._dtype_code = _lib.DTYPES[dtype]
+        self._small_batch_plan = bool(small_batch_plan)    # bf16 only: split-K plan for batches of 1 - 8 (yolo_net_set_small_batch_plan)
         self._net = None
         self._ws = None
         self._vars = None
@@ -107,6 +108,8 @@ class yolo_v2(object):
         _lib.check(_lib.lib().yolo2_net_create(self.num_class, self.box_per_cell, self._dtype_code,
                                                stream.ctypes.data, stream.size, ctypes.byref(h)))
         self._net = h
+        if self._small_batch_plan:
+            _lib.check(_lib.lib().yolo_net_set_small_batch_plan(self._net, 1))
         self._vars = split_variables(stream, self.num_class, self.box_per_cell)
         return self
 
