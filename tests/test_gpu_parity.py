@@ -578,7 +578,7 @@ def test_load_state_equals_load_weight_stream(net_f32, weight_stream, tmp_path):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("cfg", ["5", "26", "61", "75", "81", "88", "96", "97", "98", "99"])
+@pytest.mark.parametrize("cfg", ["5", "26", "61", "75", "81", "88", "96", "97", "98", "99", "115"])
 def test_alternative_conv_tilings_vs_oracle(net_bf16, oracle, oracle_params, cfg):
     """The alternates the shipped library keeps beside its default tile choice (yolo_debug_set_conv_cfg: 5 = im2col kernel with
     the LDS epilogue, 26 = 16-wave halo tile, 61 = 256 x 128 halo tile on every 3x3 stride-1 layer, 75 = halo tiles with the

@@ -1794,6 +1794,9 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
         // 256 x 128 tile, 8 waves of 64 x 64 on 16x16x32 MFMAs, wave-private epilogue, two workgroups per CU (round 2:
         // +9 % end to end over 24 / 28 on the 13x13 .. 52x52 maps)
         else if (halo_ok && BF16 && k.W <= 16) cfg = 68;     // 13x13: 128 x 128 tiles of 4 such waves fill the CUs more evenly
+        // 52 x 52: the same tile as four waves of 64 x 128 (0.4 - 0.7 % per step over 61 in eleven interleaved A/B rounds; at 26 x 26 no
+        // resolvable difference, at 13 x 13 worse)
+        else if (halo_ok && BF16 && k.W > 32 && k.W <= 52) cfg = 115;
         else if (halo_ok && BF16 && k.W <= 52) cfg = 61;
         else if (halo_ok && k.W <= 32) cfg = 24;
         // larger maps: a single patch buffer keeps two 128x128 workgroups per CU (measured 10 % faster than the
@@ -1819,6 +1822,11 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
         // patch buffer + wave-private epilogue: <= 80 KB of LDS up to W = 52 and <= 128 VGPRs, so two workgroups per CU
         case 61: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 0, 4>(k, stream);
         case 68: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2>(k, stream);   // 4 waves of 64 x 64, up to three workgroups per CU
+        // 256 x 128 tile as FOUR waves of 64 x 128: a wave covers all 128 channels of its rows, 0.375 instead of 0.5 LDS fragment reads
+        // per MFMA and half the waves at every barrier; 243 VGPRs = two waves per SIMD, two workgroups per CU (78 KB at 52 x 52)
+        case 115:
+            if constexpr (BF16) return launch_halo<true, 256, 128, 4, 1, true, 16, 0, 2>(k, stream);
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 69: return launch_halo<BF16, 128, 128, 4, 2, true, 16, 0, 1>(k, stream);   // 28 on 16x16x32 with the wave-private epilogue
         case 72: return launch_halo<BF16, 256, 128, 4, 2, true, 16, 3, 4>(k, stream);   // 61 / 68 / 69 with the register epilogue
         case 73: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 3, 2>(k, stream);
@@ -1856,6 +1864,24 @@ static int launch_dtype(const ConvK& k_in, hipStream_t stream) {
             }
             return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 112: return launch_halo<BF16, 128, 128, 2, 2, true, 16, 0, 2, 3>(k, stream);   // 68 with a three-deep ring
+        case 117: case 118:                                                 // 256 x 256 tile, one workgroup per CU: four waves of 128 x 128 / eight of 64 x 128
+            if constexpr (BF16) {
+                if (k.Cout % 256 == 0) {
+                    if (cfg == 117) return launch_halo<true, 256, 256, 2, 2, true, 16, 0, 1>(k, stream);
+                    return launch_halo<true, 256, 256, 4, 2, true, 16, 0, 2>(k, stream);
+                }
+            }
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
+        case 120: case 121:
+            if constexpr (BF16) {
+                if (cfg == 120) return launch_halo<true, 512, 128, 8, 1, true, 16, 0, 2>(k, stream);   // 115 as one workgroup of eight waves per CU
+                return launch_halo<true, 256, 128, 4, 1, true, 16, 3, 2>(k, stream);                  // 115 with the register epilogue
+            }
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
+        case 119: return launch_halo<BF16, 256, 128, 2, 2, true, 16, 0, 2>(k, stream);   // four waves of 128 x 64
+        case 116:                                                           // 115 as 128 x 128 workgroups of two waves (13 x 13: +6 % per step)
+            if constexpr (BF16) return launch_halo<true, 128, 128, 2, 1, true, 16, 0, 2>(k, stream);
+            return launch_halo<BF16, 128, 128, 4, 2>(k, stream);
         case 113: case 114:                                                 // 512 x 128 tile, 16 waves of 64 x 64, one workgroup per CU: half the weight stream per MFMA of 61
             if constexpr (BF16) {
                 if (cfg == 113) return launch_halo<true, 512, 128, 8, 2, true, 16, 0, 4, 2>(k, stream);
